@@ -1,0 +1,158 @@
+/*
+ * pt_api.h -- C ABI of libpathtracer_amd.so, the MI355X (gfx950) wavefront path tracer.
+ *
+ * The reference program has no FFI: its host code reaches the GPU through device-side `new`
+ * behind <<<1,1>>> kernels and one `render` launch.  Each entry point below names the reference
+ * interface (file:line, relative to the reference tree) whose job it takes over.
+ *
+ * Conventions: plain C types, opaque context handle, every call returns a pt_status and never
+ * exits the process (the reference's checkCudaErrors, commons.h:68-77, prints and exit(99)s).
+ * The caller owns host buffers; the library owns device memory except where a parameter is
+ * documented as a caller-provided device pointer.  One context serves one GPU and is used from
+ * one host thread at a time.  Multi-GPU jobs run one process (one context) per GPU and combine the
+ * linear accumulation buffers themselves (RCCL all-reduce), see pt_render_device.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = 1,   /* bad argument or scene description */
+    PT_ERR_NO_SCENE = 2,  /* render / trace before pt_scene_upload */
+    PT_ERR_DEVICE = 3,    /* a HIP call failed; pt_last_error() has the text */
+    PT_ERR_LIMIT = 4      /* a documented size limit was exceeded */
+} pt_status;
+
+/* Object tags: the reference's hittable subclasses (sphere.h:11, aarect.h:14,115,207, cone.h:11,
+ * cylinder.h:11), dispatched by tag instead of by vtable. */
+enum { PT_SPHERE = 0, PT_XY_RECT = 1, PT_XZ_RECT = 2, PT_YZ_RECT = 3, PT_CONE = 4, PT_CYLINDER = 5, PT_N_PRIM_TYPES = 6 };
+/* Material tags: material.h:80,141,212,284. */
+enum { PT_LAMBERTIAN = 0, PT_METAL = 1, PT_DIELECTRIC = 2, PT_DIFFUSE_LIGHT = 3, PT_N_MAT_TYPES = 4 };
+
+/* camera.h:125-145: the seven basis vectors and the lens radius of a constructed camera. */
+typedef struct pt_camera {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius;
+} pt_camera;
+
+/* The flattened world: what scene.h:37-45 builds with one cudaMalloc + one <<<1,1>>> kernel per
+ * object.  Borrowed host pointers, copied before pt_scene_upload returns.
+ *   prim_param, six floats per object, in list order (hittable_list.h:76):
+ *     sphere   cx cy cz radius - -                 (sphere.h:78-82)
+ *     xy_rect  x0 x1 y0 y1 k -   xz_rect x0 x1 z0 z1 k -   yz_rect y0 y1 z0 z1 k -   (aarect.h:108,200,291)
+ *     cone     cx cy cz height radius tangens      (cone.h:86-98; tangens = (r/h)*(r/h), cone.h:30)
+ *     cylinder cx cy cz height radius -            (cylinder.h:85-93)
+ *   mat_param, four floats per material:
+ *     lambertian r g b - ; metal r g b fuzz ; dielectric ir - - - ; diffuse_light r g b -   (material.h:134,201-205,277,339)
+ */
+typedef struct pt_scene_desc {
+    uint32_t n_prims;
+    const uint8_t *prim_type;
+    const float *prim_param;
+    const uint32_t *prim_material;
+    uint32_t n_materials;
+    const uint8_t *mat_type;
+    const float *mat_param;
+    pt_camera camera;
+    float background[3]; /* scene.h:311 */
+} pt_scene_desc;
+
+/* hit_record (hittable.h:15-33) plus the winning list index. */
+typedef struct pt_hit {
+    float t;
+    uint32_t prim; /* index in list order; 0xFFFFFFFF on a miss */
+    float n[3];    /* face-forwarded normal */
+    uint32_t front;
+    float p[3];
+    uint32_t flags; /* bit 0: resolved by the exact list-order scan */
+} pt_hit;
+
+enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1 };
+
+typedef struct pt_render_params {
+    int32_t width, height;
+    uint32_t spp;           /* samples this call renders per pixel */
+    uint32_t sample_offset; /* absolute index of the first of them: shards of one image use disjoint ranges */
+    int32_t max_depth;      /* ray_color's depth argument: 5 in the reference (main.cu:93) */
+    uint64_t seed;          /* the reference seeds curand with 1984 + pixel (main.cu:34) */
+    uint32_t samples_per_pass; /* 0 = let the library choose how many samples of every pixel are in flight */
+    uint32_t flags;            /* PT_RENDER_* */
+} pt_render_params;
+
+enum {
+    PT_RENDER_STAGE_TIMES = 1u, /* time every kernel with events (slower; fills pt_stats.ms_*) */
+    PT_RENDER_NO_SORT = 2u,     /* shade in queue order instead of material-sorted order */
+    PT_RENDER_COUNT_TESTS = 4u  /* count box / object tests per ray (slower; fills pt_stats.box_tests / prim_tests) */
+};
+
+typedef struct pt_stats {
+    uint64_t rays;         /* nearest-hit queries: one per (*world)->hit call at main.cu:54 */
+    uint64_t primary_rays;
+    uint64_t box_tests, prim_tests; /* only with PT_RENDER_COUNT_TESTS */
+    uint64_t exact_fallbacks;       /* rays resolved by the list-order scan */
+    double ms_total;                /* device time of the whole call (events on the call's stream) */
+    double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES */
+    uint32_t launches_intersect;
+    uint32_t passes;
+} pt_stats;
+
+typedef struct pt_context pt_context;
+
+/* Replaces the implicit device 0 / cudaDeviceReset life cycle of main.cu:106-220. */
+pt_status pt_context_create(int device_id, pt_context **out);
+void pt_context_destroy(pt_context *ctx);
+/* Text of the last failure on this context ("" if none); valid until the next call on it. */
+const char *pt_last_error(const pt_context *ctx);
+
+/* camera::camera (camera.h:38-62), host side, fp32, same operation order. */
+pt_status pt_camera_look_at(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov_deg,
+                            float aspect_ratio, float aperture, float focus_dist, pt_camera *out);
+
+/* Replaces the upload sequence of scene.h:20-58 (create_material_on_gpu / create_hittable_on_gpu /
+ * hittable_list::copy_list_to_gpu / create_camera_on_gpu): flattens to SoA records, builds the BVH
+ * over the reference's bounding_box() volumes (aabb.h, sphere.h:112-117, aarect.h:45-50, cone.h:142-147,
+ * cylinder.h:133-138) and copies everything to the device. */
+pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc);
+
+/* hittable_list::hit (hittable_list.h:87-101) for n rays.  o_xyz / d_xyz / out are host buffers.
+ * mode PT_TRACE_BVH is the production traversal, PT_TRACE_LINEAR the list-order scan on the GPU. */
+pt_status pt_trace_rays(pt_context *ctx, const float *o_xyz, const float *d_xyz, size_t n, float t_min, float t_max,
+                        int mode, pt_hit *out);
+/* Same with device pointers, enqueued on `stream` (a hipStream_t; NULL = the default stream). */
+pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o_xyz, const float *d_d_xyz, size_t n, float t_min,
+                               float t_max, int mode, pt_hit *d_out, void *stream);
+
+/* render (main.cu:81-100) without its final division and gamma: adds, for every pixel, the sum of
+ * ray_color over samples [sample_offset, sample_offset + spp) into rgb_sum (width*height*3 fp32, pixel
+ * index j*width+i as main.cu:86).  pt_render zero-fills and writes a host buffer; pt_render_device ADDS
+ * into a caller-provided device buffer on `stream`, so that shards of one image on several GPUs can be
+ * combined with one all-reduce before pt_film_finalize.  stats may be NULL. */
+pt_status pt_render(pt_context *ctx, const pt_render_params *params, float *rgb_sum_host, pt_stats *stats);
+pt_status pt_render_device(pt_context *ctx, const pt_render_params *params, float *d_rgb_sum, void *stream,
+                           pt_stats *stats);
+
+/* main.cu:95-98 and :192-205: mean over total_spp (multiply by the reciprocal, vec3.h:136-138), sqrt
+ * gamma, then int(256*clamp(c,0,0.999)) with rows written top-down from j = H-1.  Host buffers;
+ * rgb_gamma (bottom-up, like fb) and rgb8 (top-down, like the BMP payload) may each be NULL. */
+pt_status pt_film_finalize(const float *rgb_sum, int32_t width, int32_t height, uint32_t total_spp, float *rgb_gamma,
+                           uint8_t *rgb8);
+
+/* BVH introspection for host-side tests (no GPU needed): builds the same tree pt_scene_upload
+ * builds.  nodes_out receives n_nodes*16 floats/ints (64-byte records), order_out n_prims list
+ * indices in leaf order.  Pass NULLs to query the sizes. */
+pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
+                            uint32_t *order_out);
+
+/* Library build id, e.g. "pathtracer_amd 0.1 gfx950". */
+const char *pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,248 @@
+"""ctypes binding of libpathtracer_amd.so (include/pt_api.h).
+
+This is the only way Python reaches the GPU path.  There is no CPU fallback: if the shared
+library is missing, or no GPU is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
+
+PT_OK = 0
+STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ERR_DEVICE", 4: "PT_ERR_LIMIT"}
+
+SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
+LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
+TRACE_BVH, TRACE_LINEAR = 0, 1
+RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS = 1, 2, 4
+NO_PRIM = 0xFFFFFFFF
+FLT_MAX = float(np.finfo(np.float32).max)
+
+EXPORTS = [
+    "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload",
+    "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
+    "pt_bvh_build_host", "pt_version",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), text))
+        self.status = status
+
+
+class PtCamera(C.Structure):
+    _fields_ = [(n, C.c_float * 3) for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")] + [
+        ("lens_radius", C.c_float)
+    ]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [
+        ("n_prims", C.c_uint32), ("prim_type", C.c_void_p), ("prim_param", C.c_void_p), ("prim_material", C.c_void_p),
+        ("n_materials", C.c_uint32), ("mat_type", C.c_void_p), ("mat_param", C.c_void_p),
+        ("camera", PtCamera), ("background", C.c_float * 3),
+    ]
+
+
+class PtRenderParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_uint32), ("sample_offset", C.c_uint32),
+        ("max_depth", C.c_int32), ("seed", C.c_uint64), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class PtStats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("box_tests", C.c_uint64), ("prim_tests", C.c_uint64),
+        ("exact_fallbacks", C.c_uint64), ("ms_total", C.c_double), ("ms_raygen", C.c_double),
+        ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
+        ("launches_intersect", C.c_uint32), ("passes", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HIT_DTYPE = np.dtype(
+    [("t", "<f4"), ("prim", "<u4"), ("n", "<f4", (3,)), ("front", "<u4"), ("p", "<f4", (3,)), ("flags", "<u4")]
+)
+NODE_DTYPE = np.dtype(
+    [("lo0", "<f4", (3,)), ("c0", "<i4"), ("hi0", "<f4", (3,)), ("c1", "<i4"), ("lo1", "<f4", (3,)), ("pad0", "<u4"),
+     ("hi1", "<f4", (3,)), ("pad1", "<u4")]
+)
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libpathtracer_amd.so is missing (%s): build it with `make -C pathtracer_amd/csrc`; "
+                "there is no CPU fallback" % LIB_PATH
+            )
+        L = C.CDLL(LIB_PATH)
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_last_error.argtypes = [C.c_void_p]
+        L.pt_version.restype = C.c_char_p
+        L.pt_context_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.pt_context_destroy.argtypes = [C.c_void_p]
+        L.pt_context_destroy.restype = None
+        L.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
+        L.pt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.pt_trace_rays_device.argtypes = L.pt_trace_rays.argtypes + [C.c_void_p]
+        L.pt_render.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.POINTER(PtStats)]
+        L.pt_render_device.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p, C.POINTER(PtStats)]
+        L.pt_film_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.pt_camera_look_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(PtCamera)]
+        L.pt_bvh_build_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def version():
+    return lib().pt_version().decode()
+
+
+def _f3(a):
+    return (C.c_float * 3)(*[float(x) for x in a])
+
+
+def camera_look_at(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
+    """camera::camera (camera.h:38-62) through the library."""
+    cam = PtCamera()
+    st = lib().pt_camera_look_at(_f3(lookfrom), _f3(lookat), _f3(vup), vfov, aspect, aperture, focus_dist, C.byref(cam))
+    if st != PT_OK:
+        raise PtError(st, "pt_camera_look_at")
+    return cam
+
+
+def camera_fields(cam):
+    d = {k: np.array(list(getattr(cam, k)), dtype=np.float32) for k in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")}
+    d["lens_radius"] = np.float32(cam.lens_radius)
+    return d
+
+
+class SceneDesc:
+    """Owns the flattened arrays of a scene and exposes them as a pt_scene_desc."""
+
+    def __init__(self, prim_type, prim_param, prim_material, mat_type, mat_param, camera, background=(0, 0, 0)):
+        self.prim_type = np.ascontiguousarray(prim_type, dtype=np.uint8)
+        self.prim_param = np.ascontiguousarray(prim_param, dtype=np.float32).reshape(-1, 6)
+        self.prim_material = np.ascontiguousarray(prim_material, dtype=np.uint32)
+        self.mat_type = np.ascontiguousarray(mat_type, dtype=np.uint8)
+        self.mat_param = np.ascontiguousarray(mat_param, dtype=np.float32).reshape(-1, 4)
+        if not (len(self.prim_type) == len(self.prim_param) == len(self.prim_material)):
+            raise ValueError("object arrays differ in length")
+        if len(self.mat_type) != len(self.mat_param):
+            raise ValueError("material arrays differ in length")
+        d = PtSceneDesc()
+        d.n_prims = len(self.prim_type)
+        d.prim_type = self.prim_type.ctypes.data
+        d.prim_param = self.prim_param.ctypes.data
+        d.prim_material = self.prim_material.ctypes.data
+        d.n_materials = len(self.mat_type)
+        d.mat_type = self.mat_type.ctypes.data
+        d.mat_param = self.mat_param.ctypes.data
+        d.camera = camera
+        d.background = _f3(background)
+        self.c = d
+
+
+def bvh_build_host(desc):
+    """Builds the tree pt_scene_upload builds, on the host; returns (nodes, order, max_depth)."""
+    n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+    st = lib().pt_bvh_build_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), None, None)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_build_host")
+    nodes = np.zeros(n_nodes.value, dtype=NODE_DTYPE)
+    order = np.zeros(desc.c.n_prims, dtype=np.uint32)
+    st = lib().pt_bvh_build_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), nodes.ctypes.data, order.ctypes.data)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_build_host")
+    return nodes, order, depth.value
+
+
+def film_finalize(rgb_sum, total_spp):
+    """main.cu:95-98 and :192-205: returns (gamma image bottom-up float32, 8-bit image top-down)."""
+    rgb_sum = np.ascontiguousarray(rgb_sum, dtype=np.float32)
+    h, w, _ = rgb_sum.shape
+    gamma = np.zeros((h, w, 3), dtype=np.float32)
+    rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+    st = lib().pt_film_finalize(rgb_sum.ctypes.data, w, h, total_spp, gamma.ctypes.data, rgb8.ctypes.data)
+    if st != PT_OK:
+        raise PtError(st, "pt_film_finalize")
+    return gamma, rgb8
+
+
+class Context:
+    """One GPU, one scene at a time (pt_context)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        st = lib().pt_context_create(device, C.byref(self._h))
+        if st != PT_OK:
+            raise PtError(st, "pt_context_create(device=%d): no usable GPU" % device)
+
+    def close(self):
+        if self._h:
+            lib().pt_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != PT_OK:
+            raise PtError(st, lib().pt_last_error(self._h).decode())
+
+    def upload(self, desc):
+        self._check(lib().pt_scene_upload(self._h, C.byref(desc.c)))
+
+    def trace(self, o, d, t_min=0.001, t_max=FLT_MAX, mode=TRACE_BVH):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        if len(o) != len(d):
+            raise ValueError("origins and directions differ in length")
+        out = np.zeros(len(o), dtype=HIT_DTYPE)
+        self._check(lib().pt_trace_rays(self._h, o.ctypes.data, d.ctypes.data, len(o), t_min, t_max, mode, out.ctypes.data))
+        return out
+
+    def trace_device(self, d_o, d_d, n, d_out, stream=0, t_min=0.001, t_max=FLT_MAX, mode=TRACE_BVH):
+        self._check(lib().pt_trace_rays_device(self._h, d_o, d_d, n, t_min, t_max, mode, d_out, stream))
+
+    @staticmethod
+    def params(width, height, spp, max_depth, seed=1984, sample_offset=0, samples_per_pass=0, flags=0):
+        p = PtRenderParams()
+        p.width, p.height, p.spp, p.sample_offset = width, height, spp, sample_offset
+        p.max_depth, p.seed, p.samples_per_pass, p.flags = max_depth, seed, samples_per_pass, flags
+        return p
+
+    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, samples_per_pass=0, flags=0):
+        """Returns (rgb_sum[h, w, 3] float32 linear sums, stats dict)."""
+        p = self.params(width, height, spp, max_depth, seed, sample_offset, samples_per_pass, flags)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        stats = PtStats()
+        self._check(lib().pt_render(self._h, C.byref(p), out.ctypes.data, C.byref(stats)))
+        return out, stats.as_dict()
+
+    def render_device(self, params, d_rgb_sum, stream=0, want_stats=False):
+        """Adds into a device buffer (e.g. a torch tensor's data_ptr()) on `stream`."""
+        stats = PtStats() if want_stats else None
+        self._check(lib().pt_render_device(self._h, C.byref(params), d_rgb_sum, stream, C.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None

@@ -1,0 +1,235 @@
+// pt_bvh.cpp -- binned-SAH BVH builder (host).  The reference declares aabb / bounding_box()
+// (aabb.h:27-101 and every hittable) but never builds a hierarchy from them: its world is one
+// linear hittable_list scan (hittable_list.h:92-98).  This builder is what turns those volumes
+// into the flattened tree the gfx950 traversal kernel walks.
+#include "pt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+namespace pt {
+
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kMedianDepth = 40; // beyond this depth split at the object median (bounds the stack)
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+inline void box_empty(Box &b)
+{
+    for (int a = 0; a < 3; ++a) { b.lo[a] = kInf; b.hi[a] = -kInf; }
+}
+inline void box_grow(Box &b, const Box &o)
+{
+    for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], o.lo[a]); b.hi[a] = std::max(b.hi[a], o.hi[a]); }
+}
+inline float box_half_area(const Box &b)
+{
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct Builder {
+    const std::vector<Box> &boxes;
+    std::vector<float> cx[3];
+    std::vector<uint32_t> &order;
+    std::vector<HostNode> &nodes;
+    uint32_t leaf_max;
+    uint32_t max_depth = 0;
+
+    Builder(const std::vector<Box> &b, std::vector<uint32_t> &o, std::vector<HostNode> &n, uint32_t lm)
+        : boxes(b), order(o), nodes(n), leaf_max(lm)
+    {
+        for (int a = 0; a < 3; ++a) {
+            cx[a].resize(b.size());
+            for (size_t i = 0; i < b.size(); ++i) cx[a][i] = 0.5f * b[i].lo[a] + 0.5f * b[i].hi[a];
+        }
+    }
+
+    Box range_box(uint32_t first, uint32_t count) const
+    {
+        Box r;
+        box_empty(r);
+        for (uint32_t i = first; i < first + count; ++i) box_grow(r, boxes[order[i]]);
+        return r;
+    }
+
+    static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+    // Chooses where to cut [first, first+count); returns the size of the left part (0 < nl < count).
+    uint32_t split(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        float clo[3] = {kInf, kInf, kInf}, chi[3] = {-kInf, -kInf, -kInf};
+        for (uint32_t i = first; i < first + count; ++i)
+            for (int a = 0; a < 3; ++a) {
+                float c = cx[a][order[i]];
+                clo[a] = std::min(clo[a], c);
+                chi[a] = std::max(chi[a], c);
+            }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = kInf;
+        if (depth < kMedianDepth) {
+            for (int a = 0; a < 3; ++a) {
+                float ext = chi[a] - clo[a];
+                if (!(ext > 0) || !std::isfinite(ext)) continue;
+                float scale = (float)kBins / ext;
+                Box bb[kBins];
+                uint32_t bn[kBins] = {0};
+                for (int b = 0; b < kBins; ++b) box_empty(bb[b]);
+                for (uint32_t i = first; i < first + count; ++i) {
+                    uint32_t id = order[i];
+                    int b = std::min(kBins - 1, std::max(0, (int)((cx[a][id] - clo[a]) * scale)));
+                    bn[b]++;
+                    box_grow(bb[b], boxes[id]);
+                }
+                float right_area[kBins];
+                uint32_t right_n[kBins];
+                Box acc;
+                box_empty(acc);
+                uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    box_grow(acc, bb[b]);
+                    n += bn[b];
+                    right_area[b] = box_half_area(acc);
+                    right_n[b] = n;
+                }
+                box_empty(acc);
+                n = 0;
+                for (int b = 0; b < kBins - 1; ++b) { // cut between bin b and b+1
+                    box_grow(acc, bb[b]);
+                    n += bn[b];
+                    if (n == 0 || right_n[b + 1] == 0) continue;
+                    float cost = box_half_area(acc) * (float)n + right_area[b + 1] * (float)right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            float ext = chi[best_axis] - clo[best_axis];
+            float scale = (float)kBins / ext, lo = clo[best_axis];
+            const std::vector<float> &c = cx[best_axis];
+            int bb = best_bin;
+            auto mid = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t id) {
+                int b = std::min(kBins - 1, std::max(0, (int)((c[id] - lo) * scale)));
+                return b <= bb;
+            });
+            uint32_t nl = (uint32_t)(mid - (order.begin() + first));
+            if (nl > 0 && nl < count) return nl;
+        }
+        // object median along the widest centroid axis (also the fallback for coincident centroids)
+        int axis = 0;
+        float w = -1.0f;
+        for (int a = 0; a < 3; ++a) {
+            float e = chi[a] - clo[a];
+            if (e > w) { w = e; axis = a; }
+        }
+        uint32_t nl = count / 2;
+        const std::vector<float> &c = cx[axis];
+        std::nth_element(order.begin() + first, order.begin() + first + nl, order.begin() + first + count,
+                         [&](uint32_t x, uint32_t y) { return c[x] < c[y] || (c[x] == c[y] && x < y); });
+        return nl;
+    }
+
+    // Builds the subtree over [first, first+count) (count > leaf_max) and returns its node index.
+    int32_t build_inner(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        max_depth = std::max(max_depth, depth + 1);
+        uint32_t nl = split(first, count, depth);
+        uint32_t nr = count - nl;
+        int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box bl = range_box(first, nl), br = range_box(first + nl, nr);
+        int32_t c0 = nl > leaf_max ? build_inner(first, nl, depth + 1) : leaf_ref(first, nl);
+        int32_t c1 = nr > leaf_max ? build_inner(first + nl, nr, depth + 1) : leaf_ref(first + nl, nr);
+        HostNode &n = nodes[me];
+        for (int a = 0; a < 3; ++a) {
+            n.lo0[a] = bl.lo[a]; n.hi0[a] = bl.hi[a];
+            n.lo1[a] = br.lo[a]; n.hi1[a] = br.hi[a];
+        }
+        n.c0 = c0;
+        n.c1 = c1;
+        n.pad0 = n.pad1 = 0;
+        return me;
+    }
+};
+
+} // namespace
+
+bool prim_box(uint8_t type, const float *q, Box &b)
+{
+    const float pad_rect = 0.0001f; // aarect.h:48,147,232
+    switch (type) {
+    case PT_SPHERE: { // sphere.h:112-117 (|radius|: a negative radius would invert the reference's box)
+        float r = std::fabs(q[3]);
+        for (int a = 0; a < 3; ++a) { b.lo[a] = q[a] - r; b.hi[a] = q[a] + r; }
+        break;
+    }
+    case PT_XY_RECT: // aarect.h:45-50
+        b.lo[0] = q[0]; b.hi[0] = q[1]; b.lo[1] = q[2]; b.hi[1] = q[3]; b.lo[2] = q[4] - pad_rect; b.hi[2] = q[4] + pad_rect;
+        break;
+    case PT_XZ_RECT: // aarect.h:144-149
+        b.lo[0] = q[0]; b.hi[0] = q[1]; b.lo[2] = q[2]; b.hi[2] = q[3]; b.lo[1] = q[4] - pad_rect; b.hi[1] = q[4] + pad_rect;
+        break;
+    case PT_YZ_RECT: // aarect.h:229-234
+        b.lo[1] = q[0]; b.hi[1] = q[1]; b.lo[2] = q[2]; b.hi[2] = q[3]; b.lo[0] = q[4] - pad_rect; b.hi[0] = q[4] + pad_rect;
+        break;
+    case PT_CONE:     // cone.h:142-147
+    case PT_CYLINDER: // cylinder.h:133-138
+    {
+        float r = std::fabs(q[4]), h = q[3];
+        b.lo[0] = q[0] - r; b.hi[0] = q[0] + r;
+        b.lo[2] = q[2] - r; b.hi[2] = q[2] + r;
+        b.lo[1] = q[1]; b.hi[1] = q[1] + h;
+        break;
+    }
+    default: return false;
+    }
+    float m = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        if (b.lo[a] > b.hi[a]) std::swap(b.lo[a], b.hi[a]);
+        if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) return false;
+        m = std::max(m, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+    }
+    // The reference computes hit points in fp32 from coordinates of magnitude ~m, so an accepted
+    // hit can sit a few ulp(m) outside the exact volume; 2^-17 * m is hundreds of ulps.
+    float pad = m * (1.0f / 131072.0f) + 1e-30f;
+    for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
+    return true;
+}
+
+std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
+{
+    if (d.n_prims == 0) return "scene has no objects";
+    if (d.n_prims >= (1u << 28)) return "too many objects (limit 2^28 - 1)";
+    if (leaf_max < 1 || leaf_max > 8) return "leaf_max must be 1..8";
+    std::vector<Box> boxes(d.n_prims);
+    for (uint32_t i = 0; i < d.n_prims; ++i)
+        if (!prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, boxes[i]))
+            return "object " + std::to_string(i) + " has an unknown tag or non-finite parameters";
+    out.order.resize(d.n_prims);
+    std::iota(out.order.begin(), out.order.end(), 0u);
+    out.nodes.clear();
+    out.nodes.reserve(d.n_prims / 2 + 2);
+    Builder b(boxes, out.order, out.nodes, leaf_max);
+    if (d.n_prims > leaf_max) {
+        b.build_inner(0, d.n_prims, 0);
+    } else { // one leaf: a root whose second child is absent
+        HostNode n{};
+        Box bl = b.range_box(0, d.n_prims);
+        for (int a = 0; a < 3; ++a) {
+            n.lo0[a] = bl.lo[a]; n.hi0[a] = bl.hi[a];
+            n.lo1[a] = kInf; n.hi1[a] = -kInf;
+        }
+        n.c0 = Builder::leaf_ref(0, d.n_prims);
+        n.c1 = Builder::leaf_ref(0, 1);
+        out.nodes.push_back(n);
+        b.max_depth = 1;
+    }
+    out.max_depth = b.max_depth;
+    return "";
+}
+
+} // namespace pt

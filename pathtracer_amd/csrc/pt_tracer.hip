@@ -1,0 +1,982 @@
+// pt_tracer.hip -- gfx950 kernels and the C ABI of libpathtracer_amd.so.
+//
+// The reference renders with one thread per pixel that loops over samples and recurses through
+// virtual hit()/scatter() calls (main.cu:81-100, :46-65).  Here the same path is a wavefront
+// pipeline over queues of path records:
+//
+//   k_raygen      camera::get_ray for every (pixel, sample) of a pass          (camera.h:88-96)
+//   k_intersect   hittable_list::hit through a flattened BVH                   (hittable_list.h:87-101)
+//   k_shade       material::emitted / scatter, throughput update, compaction   (material.h, main.cu:59-64)
+//   k_film        adds the finished paths of a pass to the linear sum buffer   (main.cu:93)
+//
+// All kernels run a fixed-size grid that strides over a queue whose length lives in device
+// memory, so the host never waits for a count between bounces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_bvh.h"
+#include "pt_device.h"
+
+#define PT_BLOCK 256
+#define PT_WAVES (PT_BLOCK / 64)
+
+// ---------------------------------------------------------------------------------------------
+// Device-side views
+// ---------------------------------------------------------------------------------------------
+struct SceneDev {
+    const BvhNode *nodes;
+    const PrimRec *prims;      // leaf (BVH) order
+    const PrimRec *prims_list; // list order, for the exact scan
+    const float4 *mats;
+    uint32_t n_prims, n_nodes;
+    uint32_t stack_cap; // entries per lane in the LDS traversal stack
+    DeviceCamera cam;
+    float bg[3];
+};
+
+// A path record is 40 B in three planes:
+//   A = (origin.xyz, path id bits)   B = (direction.xyz, throughput.r)   C = (throughput.g, throughput.b)
+struct PathPlanes {
+    float4 *A;
+    float4 *B;
+    float2 *C;
+};
+
+struct Counters { // device memory, zeroed per call
+    unsigned long long rays, box_tests, prim_tests, exact_fallbacks;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Nearest hit
+// ---------------------------------------------------------------------------------------------
+struct HitResult {
+    float t;
+    uint32_t slot; // index into the array that was searched; PT_NO_PRIM on a miss
+};
+
+// hittable_list::hit (hittable_list.h:87-101) over the list-order records: the definition of the
+// answer.  Used by PT_TRACE_LINEAR and to resolve the rare rays whose answer depends on list order.
+PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, const Ray &r, float t_min, float t_max)
+{
+    HitResult best;
+    best.t = t_max;
+    best.slot = PT_NO_PRIM;
+    for (uint32_t i = 0; i < n; ++i) {
+        PrimRec q = list[i];
+        float t;
+        bool h;
+        switch (q.meta & 7u) {
+        case PT_SPHERE: h = hit_sphere(q, r, t_min, best.t, t); break;
+        case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best.t, t); break;
+        case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best.t, t); break;
+        case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, best.t, t); break;
+        case PT_CONE: {
+            ConeRoots cr;
+            h = cone_roots(q, r, cr) && hit_cone_ordered(cr, t_min, best.t, t);
+            break;
+        }
+        default: h = hit_cylinder(q, r, t_min, best.t, t); break;
+        }
+        if (h) {
+            best.t = t;
+            best.slot = i;
+        }
+    }
+    return best;
+}
+
+struct BoxRay {
+    float ox, oy, oz, ix, iy, iz;
+};
+
+// Conservative slab test (the role of aabb::hit, aabb.h:78-91).  It only prunes, so its arithmetic
+// is free-form; NaNs from 0*inf drop out of fminf/fmaxf, and the interval is widened by 2^-21
+// relative on both ends so that rounding here can never reject a box the exact test accepts.
+PT_DI bool box_test(const float *lo, const float *hi, const BoxRay &b, float t_min, float t_best, float &t_near)
+{
+    float t0x = (lo[0] - b.ox) * b.ix, t1x = (hi[0] - b.ox) * b.ix;
+    float t0y = (lo[1] - b.oy) * b.iy, t1y = (hi[1] - b.oy) * b.iy;
+    float t0z = (lo[2] - b.oz) * b.iz, t1z = (hi[2] - b.oz) * b.iz;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), t_min));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), t_best));
+    t_near = tn;
+    return tn * 0.99999952f <= tf * 1.00000048f;
+}
+
+// Nearest hit through the BVH, with the list scan's semantics:
+//  * an object's root is accepted under the reference's own test !(root < t_min || t_max < root)
+//    with t_max = the running nearest t, so equal t is accepted (hittable_list.h:93-95), and
+//  * of two objects at exactly equal t the LATER list index wins, as it would in a scan.
+// For every object whose accepted root does not depend on t_max this is order-independent, and the
+// traversal order of the tree is irrelevant.  The one exception is a cone whose quadratic has a < 0
+// (cone.h:117-122 then tries the larger root first): its nearer root is taken only if an EARLIER
+// list entry already produced a hit nearer than the larger root.  Such a candidate is parked and
+// decided after the traversal when that is possible from what the traversal knows; otherwise the
+// ray is flagged and re-resolved by linear_nearest().
+template <bool COUNT>
+PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float t_max, uint32_t *stack /* [sp*PT_BLOCK] */,
+                            bool &need_exact, uint32_t &n_box, uint32_t &n_prim)
+{
+    BoxRay br;
+    br.ox = r.o.x; br.oy = r.o.y; br.oz = r.o.z;
+    br.ix = 1.0f / r.d.x; br.iy = 1.0f / r.d.y; br.iz = 1.0f / r.d.z;
+
+    float best_t = t_max;
+    uint32_t best_slot = PT_NO_PRIM, best_id = 0;
+    // parked cone candidate
+    uint32_t n_pend = 0, pend_slot = 0, pend_id = 0;
+    float pend_r2 = 0.0f, pend_r1 = 0.0f;
+    need_exact = false;
+
+    uint32_t sp = 0;
+    int32_t cur = 0; // root
+    const uint32_t cap = sc.stack_cap;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            float4 a = np[0], b = np[1], c = np[2], d = np[3];
+            float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z};
+            float lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
+            int32_t c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
+            float tn0, tn1;
+            bool h0 = box_test(lo0, hi0, br, t_min, best_t, tn0);
+            bool h1 = box_test(lo1, hi1, br, t_min, best_t, tn1);
+            if (COUNT) n_box += 2;
+            if (h0 && h1) {
+                bool swap = tn1 < tn0;
+                int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                if (sp < cap) stack[(sp++) * PT_BLOCK] = (uint32_t)farc;
+                else need_exact = true; // cannot happen: cap >= tree depth; never corrupt, re-resolve instead
+                cur = nearc;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t ref = (uint32_t)~cur;
+            uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t slot = first + k;
+                const float4 *pp = reinterpret_cast<const float4 *>(sc.prims + slot);
+                float4 w0 = pp[0], w1 = pp[1];
+                PrimRec q;
+                q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                q.meta = __float_as_uint(w1.z);
+                q.id = __float_as_uint(w1.w);
+                if (COUNT) n_prim += 1;
+                float t = 0.0f;
+                bool h;
+                switch (q.meta & 7u) {
+                case PT_SPHERE: h = hit_sphere(q, r, t_min, best_t, t); break;
+                case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best_t, t); break;
+                case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best_t, t); break;
+                case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, best_t, t); break;
+                case PT_CONE: {
+                    ConeRoots cr;
+                    h = false;
+                    if (cone_roots(q, r, cr)) {
+                        if (!(cr.a < 0.0f)) {
+                            h = hit_cone_ordered(cr, t_min, best_t, t);
+                        } else {
+                            // larger root r1 first: an order-independent candidate
+                            if (!(cr.r1 < t_min || best_t < cr.r1) && cone_clip_ok(cr, cr.r1)) {
+                                h = true;
+                                t = cr.r1;
+                            }
+                            // nearer root r2: only reachable in the scan when its running t_max < r1
+                            if (!(cr.r2 < t_min || best_t < cr.r2) && !(cr.r1 < t_min) && cone_clip_ok(cr, cr.r2)) {
+                                if (t_max < cr.r1) { // no running t_max can reach r1: always the r2 branch
+                                    h = true;
+                                    t = cr.r2;
+                                } else {
+                                    if (n_pend == 0) { pend_slot = slot; pend_id = q.id; pend_r2 = cr.r2; pend_r1 = cr.r1; }
+                                    n_pend++;
+                                }
+                            }
+                        }
+                    }
+                    break;
+                }
+                default: h = hit_cylinder(q, r, t_min, best_t, t); break;
+                }
+                if (h && (t < best_t || best_slot == PT_NO_PRIM || q.id > best_id)) {
+                    best_t = t;
+                    best_slot = slot;
+                    best_id = q.id;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = (int32_t)stack[(--sp) * PT_BLOCK];
+    }
+
+    if (n_pend > 1) need_exact = true;
+    else if (n_pend == 1 && !(best_t < pend_r2)) {
+        // The parked cone is taken by the scan iff some EARLIER entry was accepted with t < pend_r1.
+        if (best_slot != PT_NO_PRIM && best_t < pend_r1) {
+            if (best_id < pend_id) { // the nearest other hit is earlier in the list: it is such an entry
+                best_t = pend_r2;
+                best_slot = pend_slot;
+            } else {
+                need_exact = true; // nearest other hit is later in the list: earlier ones unknown
+            }
+        }
+        // else: nothing at all was hit nearer than pend_r1, so the scan took the larger root: not a hit here
+    }
+    HitResult res;
+    res.t = best_t;
+    res.slot = best_slot;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small wave / block helpers
+// ---------------------------------------------------------------------------------------------
+PT_DI uint32_t lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+PT_DI unsigned long long wave_sum_u32(uint32_t v)
+{
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s; // valid in lane 0
+}
+
+PT_DI Ray load_ray_xyz(const float *o, const float *d, size_t i)
+{
+    Ray r;
+    r.o = V(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    r.d = V(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pt_trace_rays kernel
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__restrict__ o, const float *__restrict__ d,
+                                                    size_t n, float t_min, float t_max, pt_hit *__restrict__ out,
+                                                    Counters *cnt)
+{
+    extern __shared__ uint32_t s_stack[];
+    for (size_t base = (size_t)blockIdx.x * PT_BLOCK; base < n; base += (size_t)gridDim.x * PT_BLOCK) {
+        size_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        Ray r = load_ray_xyz(o, d, i);
+        HitResult h;
+        const PrimRec *arr;
+        uint32_t flags = 0;
+        if (MODE == PT_TRACE_LINEAR) {
+            h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+            arr = sc.prims_list;
+        } else {
+            bool need_exact;
+            uint32_t nb = 0, np = 0;
+            h = bvh_nearest<false>(sc, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+            arr = sc.prims;
+            if (need_exact) {
+                h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+                arr = sc.prims_list;
+                flags = 1;
+                atomicAdd(&cnt->exact_fallbacks, 1ull);
+            }
+        }
+        pt_hit res;
+        if (h.slot == PT_NO_PRIM) {
+            res.t = 0.0f; res.prim = PT_NO_PRIM; res.n[0] = res.n[1] = res.n[2] = 0.0f; res.front = 0;
+            res.p[0] = res.p[1] = res.p[2] = 0.0f;
+        } else {
+            PrimRec q = arr[h.slot];
+            v3 p, nrm;
+            bool front;
+            surface_at(q, r, h.t, p, nrm, front);
+            res.t = h.t; res.prim = q.id;
+            res.n[0] = nrm.x; res.n[1] = nrm.y; res.n[2] = nrm.z;
+            res.front = front ? 1u : 0u;
+            res.p[0] = p.x; res.p[1] = p.y; res.p[2] = p.z;
+        }
+        res.flags = flags;
+        out[i] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront integrator kernels
+// ---------------------------------------------------------------------------------------------
+struct PassDev {
+    uint32_t width, height, n_pixels;
+    uint32_t samples;       // samples of every pixel in flight in this pass
+    uint32_t sample_base;   // absolute index of the pass's first sample
+    uint32_t k0, k1;        // Philox key = seed
+    int32_t max_depth;
+};
+
+// camera::get_ray (camera.h:88-96) with the jitter of main.cu:90-91.  Path id = s*n_pixels + pixel.
+__global__ __launch_bounds__(PT_BLOCK) void k_raygen(SceneDev sc, PassDev ps, PathPlanes st, uint32_t *n_active)
+{
+    const uint32_t total = ps.samples * ps.n_pixels;
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_active[0] = total;
+    for (uint32_t id = blockIdx.x * PT_BLOCK + threadIdx.x; id < total; id += gridDim.x * PT_BLOCK) {
+        uint32_t s = id / ps.n_pixels, pixel = id - s * ps.n_pixels;
+        uint32_t j = pixel / ps.width, i = pixel - j * ps.width;
+        Rng g;
+        g.pixel = pixel; g.sample = ps.sample_base + s; g.bounce = 0; g.block = 0; g.k0 = ps.k0; g.k1 = ps.k1;
+        float u4[4];
+        rng_block(g, u4);
+        float u = ((float)i + u4[0]) / (float)ps.width;   // main.cu:90
+        float v = ((float)j + u4[1]) / (float)ps.height;  // main.cu:91
+        v3 disk = random_in_unit_disk(g);
+        const DeviceCamera &c = sc.cam;
+        v3 rd = vscale(c.lens_radius, disk);                                             // camera.h:89
+        v3 offset = vadd(vscale(rd.x, V(c.u[0], c.u[1], c.u[2])), vscale(rd.y, V(c.v[0], c.v[1], c.v[2]))); // :90
+        v3 origin = V(c.origin[0], c.origin[1], c.origin[2]);
+        v3 o = vadd(origin, offset);                                                     // camera.h:93
+        v3 dir = vsub(vsub(vadd(vadd(V(c.llc[0], c.llc[1], c.llc[2]), vscale(u, V(c.horizontal[0], c.horizontal[1], c.horizontal[2]))),
+                                vscale(v, V(c.vertical[0], c.vertical[1], c.vertical[2]))), origin), offset); // camera.h:94
+        st.A[id] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
+        st.B[id] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+        st.C[id] = make_float2(1.0f, 1.0f);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_intersect(SceneDev sc, PathPlanes st, uint2 *__restrict__ hits,
+                                                        const uint32_t *__restrict__ n_ptr, Counters *cnt)
+{
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t n = *n_ptr;
+    uint32_t nb = 0, np = 0, nf = 0;
+    for (uint32_t base = blockIdx.x * PT_BLOCK; base < n; base += gridDim.x * PT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        float4 A = st.A[i], B = st.B[i];
+        Ray r;
+        r.o = V(A.x, A.y, A.z);
+        r.d = V(B.x, B.y, B.z);
+        bool need_exact;
+        HitResult h = bvh_nearest<COUNT>(sc, r, 0.001f /* main.cu:54 */, PT_FLT_MAX /* commons.h:11 */, s_stack + threadIdx.x,
+                                         need_exact, nb, np);
+        uint32_t slot = h.slot;
+        if (need_exact) {
+            h = linear_nearest(sc.prims_list, sc.n_prims, r, 0.001f, PT_FLT_MAX);
+            // translate the list index to a leaf slot via the record's own id: list records carry their slot in .id? no:
+            // list-order records keep id = list index, so flag the slot as "list order" with the top bit.
+            slot = h.slot == PT_NO_PRIM ? PT_NO_PRIM : (h.slot | 0x80000000u);
+            nf++;
+        }
+        hits[i] = make_uint2(__float_as_uint(h.t), slot);
+    }
+    if (COUNT) {
+        unsigned long long sb = wave_sum_u32(nb), sp = wave_sum_u32(np);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&cnt->box_tests, sb);
+            atomicAdd(&cnt->prim_tests, sp);
+        }
+    }
+    if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
+}
+
+// main.cu:59-64 for every path of the queue: emitted(), scatter(), throughput, termination.
+// A path's radiance is known only when it ends -- emitted() is non-zero only for diffuse_light,
+// whose scatter() returns false (material.h:295-304) -- so it is written once, to rad[path id].
+__global__ __launch_bounds__(PT_BLOCK) void k_shade(SceneDev sc, PassDev ps, PathPlanes in, const uint2 *__restrict__ hits,
+                                                    PathPlanes out, const uint32_t *__restrict__ n_in_ptr,
+                                                    uint32_t *n_out_ptr, float *__restrict__ rad, int32_t bounce)
+{
+    __shared__ uint32_t s_cnt[PT_WAVES];
+    __shared__ uint32_t s_base;
+    const uint32_t n = *n_in_ptr;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool last = (bounce + 1 >= ps.max_depth);
+    for (uint32_t base = blockIdx.x * PT_BLOCK; base < n; base += gridDim.x * PT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        bool survive = false;
+        float4 oA, oB;
+        float2 oC;
+        if (i < n) {
+            float4 A = in.A[i], B = in.B[i];
+            float2 C = in.C[i];
+            uint2 hh = hits[i];
+            uint32_t id = __float_as_uint(A.w);
+            v3 T = V(B.w, C.x, C.y);
+            Ray r;
+            r.o = V(A.x, A.y, A.z);
+            r.d = V(B.x, B.y, B.z);
+            v3 result = V(0.0f, 0.0f, 0.0f);
+            if (hh.y == PT_NO_PRIM) {
+                result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
+            } else {
+                const PrimRec *arr = (hh.y & 0x80000000u) ? sc.prims_list : sc.prims;
+                const float4 *pp = reinterpret_cast<const float4 *>(arr + (hh.y & 0x7FFFFFFFu));
+                float4 w0 = pp[0], w1 = pp[1];
+                PrimRec q;
+                q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                q.meta = __float_as_uint(w1.z);
+                q.id = __float_as_uint(w1.w);
+                float t = __uint_as_float(hh.x);
+                v3 p, normal;
+                bool front;
+                surface_at(q, r, t, p, normal, front);
+                const uint32_t mtype = (q.meta >> 3) & 3u;
+                const float4 m = sc.mats[q.meta >> 5];
+                uint32_t s = id / ps.n_pixels, pixel = id - s * ps.n_pixels;
+                Rng g;
+                g.pixel = pixel; g.sample = ps.sample_base + s; g.bounce = (uint32_t)bounce + 1u; g.block = 0;
+                g.k0 = ps.k0; g.k1 = ps.k1;
+                v3 dir = V(0.0f, 0.0f, 0.0f), atten = V(0.0f, 0.0f, 0.0f);
+                bool scattered = false;
+                if (mtype == PT_DIFFUSE_LIGHT) { // material.h:295-304
+                    result = vmul(T, V(m.x, m.y, m.z));
+                } else if (mtype == PT_DIELECTRIC) { // material.h:223-242
+                    float ir = m.x;
+                    atten = V(1.0f, 1.0f, 1.0f);
+                    float refraction_ratio = front ? (1.0f / ir) : ir;
+                    v3 unit_direction = vunit(r.d);
+                    float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
+                    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    bool reflect_it = refraction_ratio * sin_theta > 1.0f;
+                    if (!reflect_it) { // the uniform is consumed only when refraction is possible (material.h:235)
+                        float u4[4];
+                        rng_block(g, u4);
+                        reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u4[0];
+                    }
+                    dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
+                    scattered = true;
+                } else {
+                    v3 rs = random_in_unit_sphere(g);
+                    atten = V(m.x, m.y, m.z);
+                    if (mtype == PT_LAMBERTIAN) { // material.h:90-99
+                        dir = vadd(normal, vunit(rs));
+                        if (vnear_zero(dir)) dir = normal;
+                        scattered = true;
+                    } else { // metal, material.h:155-162
+                        v3 reflected = vreflect(vunit(r.d), normal);
+                        dir = vadd(reflected, vscale(m.w, rs));
+                        scattered = vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
+                    }
+                }
+                if (scattered && !last) { // main.cu:64: attenuation * ray_color(scattered, depth - 1)
+                    survive = true;
+                    v3 Tn = vmul(T, atten);
+                    oA = make_float4(p.x, p.y, p.z, A.w);
+                    oB = make_float4(dir.x, dir.y, dir.z, Tn.x);
+                    oC = make_float2(Tn.y, Tn.z);
+                }
+                // scattered && last: the next ray_color call has depth <= 0 and returns black (main.cu:50-51)
+            }
+            if (!survive) {
+                rad[3 * (size_t)id + 0] = result.x;
+                rad[3 * (size_t)id + 1] = result.y;
+                rad[3 * (size_t)id + 2] = result.z;
+            }
+        }
+        // compaction: one atomic per block chunk
+        unsigned long long mask = __ballot(survive);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < PT_WAVES; ++w) { uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+            s_base = tot ? atomicAdd(n_out_ptr, tot) : 0u;
+        }
+        __syncthreads();
+        if (survive) {
+            uint32_t pos = s_base + s_cnt[wave] + lane_prefix(mask);
+            out.A[pos] = oA;
+            out.B[pos] = oB;
+            out.C[pos] = oC;
+        }
+        __syncthreads();
+    }
+}
+
+// col += ray_color(...) in sample order (main.cu:93), and the pass's ray count.
+__global__ __launch_bounds__(PT_BLOCK) void k_film(PassDev ps, const float *__restrict__ rad, float *__restrict__ rgb_sum,
+                                                   const uint32_t *__restrict__ n_active, Counters *cnt)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long r = 0;
+        for (int b = 0; b < ps.max_depth; ++b) r += n_active[b];
+        atomicAdd(&cnt->rays, r);
+    }
+    for (uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x; p < ps.n_pixels; p += gridDim.x * PT_BLOCK) {
+        float r = rgb_sum[3 * (size_t)p], g = rgb_sum[3 * (size_t)p + 1], b = rgb_sum[3 * (size_t)p + 2];
+        for (uint32_t s = 0; s < ps.samples; ++s) {
+            size_t id = (size_t)s * ps.n_pixels + p;
+            r += rad[3 * id];
+            g += rad[3 * id + 1];
+            b += rad[3 * id + 2];
+        }
+        rgb_sum[3 * (size_t)p] = r;
+        rgb_sum[3 * (size_t)p + 1] = g;
+        rgb_sum[3 * (size_t)p + 2] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct pt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+
+    bool has_scene = false;
+    SceneDev sc{};
+    BvhNode *d_nodes = nullptr;
+    PrimRec *d_prims = nullptr, *d_prims_list = nullptr;
+    float4 *d_mats = nullptr;
+    uint32_t max_depth_tree = 0;
+
+    // integrator workspace (grown on demand, kept across calls)
+    size_t cap_paths = 0;
+    float4 *d_A[2] = {nullptr, nullptr}, *d_B[2] = {nullptr, nullptr};
+    float2 *d_C[2] = {nullptr, nullptr};
+    uint2 *d_hits = nullptr;
+    float *d_rad = nullptr;
+    uint32_t *d_nactive = nullptr;
+    size_t cap_nactive = 0;
+    Counters *d_cnt = nullptr;
+    // pt_trace_rays staging
+    float *d_ro = nullptr, *d_rd = nullptr;
+    pt_hit *d_rh = nullptr;
+    size_t cap_rays = 0;
+    std::vector<hipEvent_t> events;
+};
+
+static pt_status fail(pt_context *ctx, pt_status st, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return st;
+}
+
+#define PT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return fail(ctx, PT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+extern "C" const char *pt_version(void) { return "pathtracer_amd 0.1 gfx950"; }
+
+extern "C" pt_status pt_context_create(int device_id, pt_context **out)
+{
+    if (!out) return PT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return PT_ERR_DEVICE;
+    pt_context *ctx = new pt_context();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return PT_ERR_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PT_ERR_DEVICE; }
+    if (hipMalloc(&ctx->d_cnt, sizeof(Counters)) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
+    *out = ctx;
+    return PT_OK;
+}
+
+static void free_scene(pt_context *ctx)
+{
+    hipFree(ctx->d_nodes); hipFree(ctx->d_prims); hipFree(ctx->d_prims_list); hipFree(ctx->d_mats);
+    ctx->d_nodes = nullptr; ctx->d_prims = ctx->d_prims_list = nullptr; ctx->d_mats = nullptr;
+    ctx->has_scene = false;
+}
+
+static void free_workspace(pt_context *ctx)
+{
+    for (int k = 0; k < 2; ++k) { hipFree(ctx->d_A[k]); hipFree(ctx->d_B[k]); hipFree(ctx->d_C[k]); ctx->d_A[k] = ctx->d_B[k] = nullptr; ctx->d_C[k] = nullptr; }
+    hipFree(ctx->d_hits); hipFree(ctx->d_rad); ctx->d_hits = nullptr; ctx->d_rad = nullptr;
+    ctx->cap_paths = 0;
+}
+
+extern "C" void pt_context_destroy(pt_context *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    free_scene(ctx);
+    free_workspace(ctx);
+    hipFree(ctx->d_nactive); hipFree(ctx->d_cnt);
+    hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
+    for (hipEvent_t e : ctx->events) hipEventDestroy(e);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// camera::camera, camera.h:38-62.  Host fp32, no contraction (this file is built with -ffp-contract=off).
+extern "C" pt_status pt_camera_look_at(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,
+                                       float aspect_ratio, float aperture, float focus_dist, pt_camera *out)
+{
+    if (!lookfrom || !lookat || !vup || !out) return PT_ERR_INVALID;
+    struct H { float x, y, z; };
+    auto sub = [](H a, H b) { return H{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto scale = [](float t, H a) { return H{t * a.x, t * a.y, t * a.z}; };
+    auto cross = [](H a, H b) { return H{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+    auto unit = [&](H a) { float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); return scale(1.0f / l, a); };
+    const float PI = 3.1415926535897932385f; // cuda_functions.h:6
+    H from{lookfrom[0], lookfrom[1], lookfrom[2]}, at{lookat[0], lookat[1], lookat[2]}, up{vup[0], vup[1], vup[2]};
+    const float theta = vfov * PI / 180.0f;
+    const float h = tanf(theta / 2.0f);
+    const float viewport_height = 2.0f * h;
+    const float viewport_width = aspect_ratio * viewport_height;
+    H w = unit(sub(from, at));
+    H u = unit(cross(up, w));
+    H v = cross(w, u);
+    H horizontal = scale(focus_dist * viewport_width, u);
+    H vertical = scale(focus_dist * viewport_height, v);
+    H llc = sub(sub(sub(from, scale(1.0f / 2.0f, horizontal)), scale(1.0f / 2.0f, vertical)), scale(focus_dist, w));
+    auto st = [](float *p, H a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; };
+    st(out->origin, from); st(out->lower_left_corner, llc); st(out->horizontal, horizontal); st(out->vertical, vertical);
+    st(out->u, u); st(out->v, v); st(out->w, w);
+    out->lens_radius = aperture / 2.0f;
+    return PT_OK;
+}
+
+static std::string validate_desc(const pt_scene_desc *d)
+{
+    if (!d) return "null scene description";
+    if (d->n_prims == 0 || !d->prim_type || !d->prim_param || !d->prim_material) return "scene has no objects";
+    if (d->n_materials == 0 || !d->mat_type || !d->mat_param) return "scene has no materials";
+    if (d->n_materials >= (1u << 27)) return "too many materials (limit 2^27 - 1)";
+    for (uint32_t i = 0; i < d->n_materials; ++i)
+        if (d->mat_type[i] >= PT_N_MAT_TYPES) return "material " + std::to_string(i) + " has an unknown tag";
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        if (d->prim_type[i] >= PT_N_PRIM_TYPES) return "object " + std::to_string(i) + " has an unknown tag";
+        // the reference indexes materials[material_index] unchecked (sphere.h:71)
+        if (d->prim_material[i] >= d->n_materials) return "object " + std::to_string(i) + " names a material that does not exist";
+    }
+    return "";
+}
+
+static void make_records(const pt_scene_desc &d, const std::vector<uint32_t> &order, std::vector<PrimRec> &leaf,
+                         std::vector<PrimRec> &list, std::vector<float4> &mats)
+{
+    list.resize(d.n_prims);
+    for (uint32_t i = 0; i < d.n_prims; ++i) {
+        PrimRec &q = list[i];
+        for (int k = 0; k < 6; ++k) q.p[k] = d.prim_param[(size_t)i * 6 + k];
+        uint32_t m = d.prim_material[i];
+        q.meta = (uint32_t)d.prim_type[i] | ((uint32_t)d.mat_type[m] << 3) | (m << 5);
+        q.id = i;
+    }
+    leaf.resize(d.n_prims);
+    for (uint32_t s = 0; s < d.n_prims; ++s) leaf[s] = list[order[s]];
+    mats.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+        const float *p = d.mat_param + (size_t)i * 4;
+        float w = p[3];
+        if (d.mat_type[i] == PT_METAL) w = w > 1.0f ? 1.0f : w; // material.h:150
+        mats[i] = make_float4(p[0], p[1], p[2], w);
+    }
+}
+
+extern "C" pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
+                                       uint32_t *order_out)
+{
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return PT_ERR_INVALID;
+    pt::BvhBuild b;
+    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    if (!e.empty()) return PT_ERR_INVALID;
+    if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
+    if (max_depth) *max_depth = b.max_depth;
+    if (nodes_out) memcpy(nodes_out, b.nodes.data(), b.nodes.size() * sizeof(pt::HostNode));
+    if (order_out) memcpy(order_out, b.order.data(), b.order.size() * sizeof(uint32_t));
+    return PT_OK;
+}
+
+extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    pt::BvhBuild b;
+    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    if (b.max_depth > 96) return fail(ctx, PT_ERR_LIMIT, "BVH deeper than 96 levels");
+    std::vector<PrimRec> leaf, list;
+    std::vector<float4> mats;
+    make_records(*desc, b.order, leaf, list, mats);
+
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipDeviceSynchronize());
+    free_scene(ctx);
+    const size_t nb = b.nodes.size() * sizeof(BvhNode), pb = leaf.size() * sizeof(PrimRec), mb = mats.size() * sizeof(float4);
+    PT_HIP(ctx, hipMalloc(&ctx->d_nodes, nb));
+    PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb));
+    PT_HIP(ctx, hipMalloc(&ctx->d_prims_list, pb));
+    PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
+    PT_HIP(ctx, hipMemcpy(ctx->d_nodes, b.nodes.data(), nb, hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_prims, leaf.data(), pb, hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_prims_list, list.data(), pb, hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_mats, mats.data(), mb, hipMemcpyHostToDevice));
+
+    SceneDev &sc = ctx->sc;
+    sc.nodes = ctx->d_nodes;
+    sc.prims = ctx->d_prims;
+    sc.prims_list = ctx->d_prims_list;
+    sc.mats = ctx->d_mats;
+    sc.n_prims = desc->n_prims;
+    sc.n_nodes = (uint32_t)b.nodes.size();
+    sc.stack_cap = std::max(8u, b.max_depth + 1);
+    const pt_camera &c = desc->camera;
+    for (int k = 0; k < 3; ++k) {
+        sc.cam.origin[k] = c.origin[k]; sc.cam.llc[k] = c.lower_left_corner[k];
+        sc.cam.horizontal[k] = c.horizontal[k]; sc.cam.vertical[k] = c.vertical[k];
+        sc.cam.u[k] = c.u[k]; sc.cam.v[k] = c.v[k];
+        sc.bg[k] = desc->background[k];
+    }
+    sc.cam.lens_radius = c.lens_radius;
+    ctx->max_depth_tree = b.max_depth;
+    ctx->has_scene = true;
+    return PT_OK;
+}
+
+static uint32_t grid_for(const pt_context *ctx, size_t n)
+{
+    size_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
+    size_t cap = (size_t)ctx->n_cu * 8;
+    return (uint32_t)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, const float *d_d, size_t n, float t_min,
+                                          float t_max, int mode, pt_hit *d_out, void *stream_)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (!d_o || !d_d || !d_out) return fail(ctx, PT_ERR_INVALID, "null ray or output buffer");
+    if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
+    hipStream_t stream = (hipStream_t)stream_;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
+    uint32_t grid = grid_for(ctx, n);
+    size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
+    if (mode == PT_TRACE_LINEAR)
+        hipLaunchKernelGGL(k_trace<PT_TRACE_LINEAR>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
+    else
+        hipLaunchKernelGGL(k_trace<PT_TRACE_BVH>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+extern "C" pt_status pt_trace_rays(pt_context *ctx, const float *o, const float *d, size_t n, float t_min, float t_max,
+                                   int mode, pt_hit *out)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (!o || !d || !out) return fail(ctx, PT_ERR_INVALID, "null ray or output buffer");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > ctx->cap_rays) {
+        hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
+        ctx->d_ro = ctx->d_rd = nullptr; ctx->d_rh = nullptr; ctx->cap_rays = 0;
+        PT_HIP(ctx, hipMalloc(&ctx->d_ro, n * 3 * sizeof(float)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_rd, n * 3 * sizeof(float)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_rh, n * sizeof(pt_hit)));
+        ctx->cap_rays = n;
+    }
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_ro, o, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->own_stream));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_rd, d, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->own_stream));
+    pt_status st = pt_trace_rays_device(ctx, ctx->d_ro, ctx->d_rd, n, t_min, t_max, mode, ctx->d_rh, ctx->own_stream);
+    if (st != PT_OK) return st;
+    PT_HIP(ctx, hipMemcpyAsync(out, ctx->d_rh, n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->own_stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+    return PT_OK;
+}
+
+static pt_status ensure_workspace(pt_context *ctx, size_t paths, size_t depth_slots)
+{
+    if (paths > ctx->cap_paths) {
+        free_workspace(ctx);
+        for (int k = 0; k < 2; ++k) {
+            PT_HIP(ctx, hipMalloc(&ctx->d_A[k], paths * sizeof(float4)));
+            PT_HIP(ctx, hipMalloc(&ctx->d_B[k], paths * sizeof(float4)));
+            PT_HIP(ctx, hipMalloc(&ctx->d_C[k], paths * sizeof(float2)));
+        }
+        PT_HIP(ctx, hipMalloc(&ctx->d_hits, paths * sizeof(uint2)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_rad, paths * 3 * sizeof(float)));
+        ctx->cap_paths = paths;
+    }
+    if (depth_slots > ctx->cap_nactive) {
+        hipFree(ctx->d_nactive);
+        ctx->d_nactive = nullptr; ctx->cap_nactive = 0;
+        PT_HIP(ctx, hipMalloc(&ctx->d_nactive, depth_slots * sizeof(uint32_t)));
+        ctx->cap_nactive = depth_slots;
+    }
+    return PT_OK;
+}
+
+struct StageTimer {
+    pt_context *ctx;
+    hipStream_t stream;
+    bool on;
+    size_t used = 0;
+    std::vector<int> stage; // per event pair
+    StageTimer(pt_context *c, hipStream_t s, bool o) : ctx(c), stream(s), on(o) {}
+    hipEvent_t get()
+    {
+        if (used == ctx->events.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            ctx->events.push_back(e);
+        }
+        return ctx->events[used++];
+    }
+    void begin(int st) { if (on) { stage.push_back(st); hipEventRecord(get(), stream); } }
+    void end() { if (on) hipEventRecord(get(), stream); }
+};
+
+extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, void *stream_,
+                                      pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (!pr || !d_rgb_sum) return fail(ctx, PT_ERR_INVALID, "null parameters or output buffer");
+    if (pr->width <= 0 || pr->height <= 0 || pr->spp == 0 || pr->max_depth <= 0)
+        return fail(ctx, PT_ERR_INVALID, "width, height, spp and max_depth must be positive");
+    if (pr->max_depth > 4096) return fail(ctx, PT_ERR_LIMIT, "max_depth above 4096");
+    const uint64_t n_pixels64 = (uint64_t)pr->width * (uint64_t)pr->height;
+    if (n_pixels64 > (1ull << 28)) return fail(ctx, PT_ERR_LIMIT, "image larger than 2^28 pixels");
+    if ((uint64_t)pr->sample_offset + pr->spp > 0xFFFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "sample index overflows 32 bits");
+    const uint32_t n_pixels = (uint32_t)n_pixels64;
+    hipStream_t stream = (hipStream_t)stream_;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+
+    // samples of every pixel in flight per pass: as many as fit the path budget
+    const uint64_t budget = 1ull << 24;
+    uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : (uint32_t)std::max<uint64_t>(1, budget / n_pixels);
+    spass = std::min(spass, pr->spp);
+    if ((uint64_t)spass * n_pixels > (1ull << 31)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass * pixels above 2^31");
+    const size_t paths = (size_t)spass * n_pixels;
+    pt_status st = ensure_workspace(ctx, paths, (size_t)pr->max_depth + 1);
+    if (st != PT_OK) return st;
+
+    const bool timed = (pr->flags & PT_RENDER_STAGE_TIMES) != 0;
+    const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
+    StageTimer tm(ctx, stream, timed);
+    hipEvent_t ev0 = tm.get(), ev1 = tm.get();
+    tm.used = 2;
+    PT_HIP(ctx, hipEventRecord(ev0, stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
+
+    PassDev ps;
+    ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
+    ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
+    ps.max_depth = pr->max_depth;
+    const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
+    uint32_t n_passes = 0, n_isect = 0;
+    for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
+        ps.samples = std::min(spass, pr->spp - done);
+        ps.sample_base = pr->sample_offset + done;
+        const size_t np = (size_t)ps.samples * n_pixels;
+        const uint32_t grid = grid_for(ctx, np);
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_nactive, 0, ((size_t)pr->max_depth + 1) * sizeof(uint32_t), stream));
+        PathPlanes cur{ctx->d_A[0], ctx->d_B[0], ctx->d_C[0]}, nxt{ctx->d_A[1], ctx->d_B[1], ctx->d_C[1]};
+        tm.begin(0);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, ctx->sc, ps, cur, ctx->d_nactive);
+        tm.end();
+        for (int32_t b = 0; b < pr->max_depth; ++b) {
+            tm.begin(1);
+            if (count)
+                hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, ctx->d_nactive + b, ctx->d_cnt);
+            else
+                hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, ctx->d_nactive + b, ctx->d_cnt);
+            tm.end();
+            ++n_isect;
+            tm.begin(2);
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, stream, ctx->sc, ps, cur, ctx->d_hits, nxt, ctx->d_nactive + b,
+                               ctx->d_nactive + b + 1, ctx->d_rad, b);
+            tm.end();
+            std::swap(cur, nxt);
+        }
+        tm.begin(3);
+        hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, n_pixels)), dim3(PT_BLOCK), 0, stream, ps, ctx->d_rad, d_rgb_sum, ctx->d_nactive, ctx->d_cnt);
+        tm.end();
+    }
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventRecord(ev1, stream));
+
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        Counters h;
+        PT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_cnt, sizeof h, hipMemcpyDeviceToHost, stream));
+        PT_HIP(ctx, hipStreamSynchronize(stream));
+        stats->rays = h.rays;
+        stats->primary_rays = (uint64_t)pr->spp * n_pixels;
+        stats->box_tests = h.box_tests;
+        stats->prim_tests = h.prim_tests;
+        stats->exact_fallbacks = h.exact_fallbacks;
+        stats->launches_intersect = n_isect;
+        stats->passes = n_passes;
+        float ms = 0.0f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+        stats->ms_total = ms;
+        if (timed) {
+            double acc[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < tm.stage.size(); ++k) {
+                float m = 0.0f;
+                PT_HIP(ctx, hipEventElapsedTime(&m, ctx->events[2 + 2 * k], ctx->events[3 + 2 * k]));
+                acc[tm.stage[k]] += m;
+            }
+            stats->ms_raygen = acc[0]; stats->ms_intersect = acc[1]; stats->ms_shade = acc[2]; stats->ms_film = acc[3];
+        }
+    }
+    return PT_OK;
+}
+
+extern "C" pt_status pt_render(pt_context *ctx, const pt_render_params *pr, float *rgb_sum_host, pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!pr || !rgb_sum_host) return fail(ctx, PT_ERR_INVALID, "null parameters or output buffer");
+    if (pr->width <= 0 || pr->height <= 0) return fail(ctx, PT_ERR_INVALID, "width and height must be positive");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)pr->width * pr->height * 3 * sizeof(float);
+    float *d_sum = nullptr;
+    PT_HIP(ctx, hipMalloc(&d_sum, bytes));
+    hipError_t e = hipMemsetAsync(d_sum, 0, bytes, ctx->own_stream);
+    pt_status st = e == hipSuccess ? pt_render_device(ctx, pr, d_sum, ctx->own_stream, stats) : fail(ctx, PT_ERR_DEVICE, hipGetErrorString(e));
+    if (st == PT_OK) {
+        e = hipMemcpyAsync(rgb_sum_host, d_sum, bytes, hipMemcpyDeviceToHost, ctx->own_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->own_stream);
+        if (e != hipSuccess) st = fail(ctx, PT_ERR_DEVICE, hipGetErrorString(e));
+    }
+    hipFree(d_sum);
+    return st;
+}
+
+// main.cu:95-98 and :192-205 (host).
+extern "C" pt_status pt_film_finalize(const float *rgb_sum, int32_t width, int32_t height, uint32_t total_spp, float *rgb_gamma,
+                                      uint8_t *rgb8)
+{
+    if (!rgb_sum || width <= 0 || height <= 0 || total_spp == 0) return PT_ERR_INVALID;
+    const float inv = 1.0f / (float)total_spp; // vec3.h:136-138: operator/= multiplies by 1/t
+    size_t w = 0;
+    for (int32_t j = height - 1; j >= 0; --j) {
+        for (int32_t i = 0; i < width; ++i) {
+            const size_t px = (size_t)j * width + i;
+            for (int c = 0; c < 3; ++c) {
+                float g = sqrtf(rgb_sum[px * 3 + c] * inv);
+                if (rgb_gamma) rgb_gamma[px * 3 + c] = g;
+                if (rgb8) {
+                    float cl = g < 0.0f ? 0.0f : (g > 0.999f ? 0.999f : g); // commons.h:58-62
+                    rgb8[w] = (uint8_t)(int)(256 * cl);
+                }
+                ++w;
+            }
+        }
+    }
+    return PT_OK;
+}

@@ -1,0 +1,148 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bars (fp32 path):
+  * nearest hit (hit/miss, t, list index, normal, point, face flag): BIT-EXACT against the oracle's
+    list-order scan on every ray of every batch (rays on which the oracle saw a NaN root are outside the
+    contract and masked; none occur in these batches unless a test says so);
+  * images: the GPU walks the same paths as the oracle (same counter-based stream), and differs only in
+    the association of the throughput product (iterative vs the reference's recursion, main.cu:64):
+    per-pixel |diff| <= 2e-5 * max(1, value) on the linear sums for >= 99.9 % of pixels (a path whose
+    Russian-doll of products rounds differently can flip a rejection-sampling decision further down;
+    such pixels are counted, not hidden) and a relative RMSE <= 1e-3.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import api, scenes
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {
+    "default": scenes.default_scene,
+    "cornell": scenes.cornell_scene,
+    "random_spheres": scenes.random_spheres_scene,
+    "mixed_1k": lambda: scenes.mixed_scene(n=1000, seed=3, extent=20.0, n_materials=64),
+}
+
+
+@pytest.fixture(scope="module", params=list(SCENES))
+def loaded(request, ctx):
+    b = SCENES[request.param]()
+    ctx.upload(b.desc())
+    return request.param, b, util.oracle_scene(b)
+
+
+def test_trace_bvh_bit_exact(loaded, ctx):
+    name, b, osc = loaded
+    o, d = util.mixed_rays(b, osc, 20000, seed=101)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d, mode=api.TRACE_BVH)
+    ok = ref["nan_flag"] == 0
+    bad = util.hits_equal(got, ref) & ok
+    assert ok.mean() > 0.999
+    assert not bad.any(), "%s: %d of %d rays differ, first %s" % (name, bad.sum(), len(o), np.flatnonzero(bad)[:5])
+    assert (ref["prim"] != api.NO_PRIM).mean() > 0.2  # the batch does exercise hits
+
+
+def test_trace_linear_bit_exact(loaded, ctx):
+    name, b, osc = loaded
+    o, d = util.mixed_rays(b, osc, 4000, seed=202)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d, mode=api.TRACE_LINEAR)
+    ok = ref["nan_flag"] == 0
+    bad = util.hits_equal(got, ref) & ok
+    assert not bad.any(), "%s: %d rays differ" % (name, bad.sum())
+
+
+def test_trace_t_range(loaded, ctx):
+    """A caller-given [t_min, t_max] is honoured exactly like hittable_list::hit's arguments."""
+    name, b, osc = loaded
+    o, d = util.mixed_rays(b, osc, 3000, seed=303)
+    for t_min, t_max in ((0.5, 3.0), (1e-3, 0.9), (2.0, 1e30)):
+        ref = osc.trace(o, d, t_min=t_min, t_max=t_max)
+        got = ctx.trace(o, d, t_min=t_min, t_max=t_max)
+        ok = ref["nan_flag"] == 0
+        assert not (util.hits_equal(got, ref) & ok).any(), (name, t_min, t_max)
+
+
+def _image_close(got, ref):
+    tol = 2e-5 * np.maximum(1.0, np.abs(ref))
+    bad_px = (np.abs(got - ref) > tol).any(axis=2)
+    rmse = float(np.sqrt(np.mean((got - ref) ** 2)) / max(1e-12, np.sqrt(np.mean(ref ** 2))))
+    return bad_px.mean(), rmse
+
+
+@pytest.mark.parametrize("depth", [5, 50])
+def test_render_default_scene(ctx, depth):
+    """BASELINE config 1: scene() at 400x225, 16 spp; depth 5 is the reference's own (main.cu:93)."""
+    b = scenes.default_scene()
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    ref, ref_rays = osc.render(400, 225, 16, depth)
+    got, st = ctx.render(400, 225, 16, depth)
+    frac, rmse = _image_close(got, ref)
+    assert st["rays"] == ref_rays or abs(st["rays"] - ref_rays) < 1e-4 * ref_rays
+    assert frac < 1e-3 and rmse < 1e-3, (frac, rmse)
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth", [("cornell", 96, 96, 8, 5), ("random_spheres", 160, 90, 4, 50), ("mixed_1k", 96, 54, 4, 8)])
+def test_render_small(ctx, name, w, h, spp, depth):
+    b = SCENES[name]()
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    ref, ref_rays = osc.render(w, h, spp, depth)
+    got, st = ctx.render(w, h, spp, depth)
+    frac, rmse = _image_close(got, ref)
+    assert abs(st["rays"] - ref_rays) <= 1e-3 * ref_rays
+    assert frac < 2e-3 and rmse < 2e-3, (name, frac, rmse)
+
+
+def test_render_full_size_crop(ctx):
+    """BASELINE config 2 at its full 1920x1080 size (2 spp): a 48x32 crop against the oracle, which
+    renders only those pixels (the stream is keyed by the absolute pixel index)."""
+    b = scenes.random_spheres_scene()
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    got, st = ctx.render(1920, 1080, 2, 50)
+    x0, y0, w, h = 900, 380, 48, 32
+    ref, _ = osc.render(1920, 1080, 2, 50, region=(x0, y0, w, h))
+    frac, rmse = _image_close(got[y0:y0 + h, x0:x0 + w], ref)
+    assert frac < 5e-3 and rmse < 5e-3, (frac, rmse)
+    assert np.isfinite(got).all() and st["rays"] > st["primary_rays"]
+
+
+def test_sample_shards_add_up(ctx):
+    """Sample-range shards (what each GPU of a node renders) sum to the unsharded image: the stream is
+    keyed by the absolute sample index, so only the fp32 association of the per-pixel sum changes."""
+    b = scenes.default_scene()
+    ctx.upload(b.desc())
+    full, st = ctx.render(200, 112, 8, 5)
+    parts = [ctx.render(200, 112, 2, 5, sample_offset=k * 2) for k in range(4)]
+    total = sum(p[0].astype(np.float64) for p in parts)
+    assert sum(p[1]["rays"] for p in parts) == st["rays"]
+    np.testing.assert_allclose(total, full, rtol=1e-5, atol=1e-6)
+
+
+def test_pass_size_does_not_matter(ctx):
+    """samples_per_pass only changes batching: the image is bit-identical."""
+    b = scenes.cornell_scene()
+    ctx.upload(b.desc())
+    a, sa = ctx.render(64, 64, 6, 5, samples_per_pass=1)
+    c, sc = ctx.render(64, 64, 6, 5, samples_per_pass=4)
+    assert sa["rays"] == sc["rays"]
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+def test_errors(ctx):
+    fresh = api.Context(0)
+    with pytest.raises(api.PtError) as e:
+        fresh.render(8, 8, 1, 5)
+    assert e.value.status == 2
+    fresh.close()
+    b = scenes.default_scene()
+    ctx.upload(b.desc())
+    with pytest.raises(api.PtError):
+        ctx.render(0, 8, 1, 5)
+    with pytest.raises(api.PtError):
+        ctx.render(8, 8, 0, 5)
