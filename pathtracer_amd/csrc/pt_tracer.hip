@@ -856,7 +856,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
     PT_HIP(ctx, hipSetDevice(ctx->device));
 
     // samples of every pixel in flight per pass: as many as fit the path budget
-    const uint64_t budget = 1ull << 24;
+    const uint64_t budget = 1ull << 27; // 134M paths in flight = 13.4 GB of queues: tail bounces are paid once per pass
     uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : (uint32_t)std::max<uint64_t>(1, budget / n_pixels);
     spass = std::min(spass, pr->spp);
     if ((uint64_t)spass * n_pixels > (1ull << 31)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass * pixels above 2^31");

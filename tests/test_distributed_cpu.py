@@ -1,0 +1,70 @@
+"""The N>1 path on CPU: two processes over gloo shard the samples of one image exactly as bench.py's
+ranks do (pathtracer_amd.distributed), all-reduce the linear accumulation buffers, and finish the film.
+The per-rank renderer here is the CPU oracle standing in for the GPU (no GPU exists in this test); what
+is under test is the sharding, the reduction and the order 'reduce first, gamma after'."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pathtracer_amd import api, distributed, scenes
+from tests import util
+
+W, H, SPP, DEPTH = 48, 27, 3, 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        osc = util.oracle_scene(scenes.default_scene())
+        if mode == "weak":
+            off, n = distributed.weak_shard(rank, world, SPP)
+        else:
+            off, n = distributed.strong_shard(rank, world, SPP)
+        img, rays = osc.render(W, H, n, DEPTH, sample0=off, threads=1)
+        acc = torch.from_numpy(img.copy())
+        distributed.all_reduce_sum(acc)
+        r = torch.tensor([rays], dtype=torch.int64)
+        dist.all_reduce(r)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "acc_%s.npy" % mode), acc.numpy())
+            np.save(os.path.join(out_dir, "rays_%s.npy" % mode), r.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(mode, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    return np.load(tmp_path / ("acc_%s.npy" % mode)), int(np.load(tmp_path / ("rays_%s.npy" % mode))[0])
+
+
+def test_weak_sharding_two_ranks(tmp_path):
+    acc, rays = _run("weak", tmp_path)
+    osc = util.oracle_scene(scenes.default_scene())
+    full, full_rays = osc.render(W, H, 2 * SPP, DEPTH)  # the image has world * spp samples
+    assert rays == full_rays
+    np.testing.assert_allclose(acc, full, rtol=1e-5, atol=1e-6)  # only the fp32 sum association differs
+    g_sharded, q_sharded = api.film_finalize(acc, 2 * SPP)  # gamma AFTER the reduction (main.cu:95-98 is non-linear)
+    g_full, q_full = api.film_finalize(full, 2 * SPP)
+    assert np.abs(q_sharded.astype(int) - q_full.astype(int)).max() <= 1
+
+
+def test_strong_sharding_two_ranks(tmp_path):
+    acc, rays = _run("strong", tmp_path)
+    osc = util.oracle_scene(scenes.default_scene())
+    full, full_rays = osc.render(W, H, SPP, DEPTH)
+    assert rays == full_rays
+    np.testing.assert_allclose(acc, full, rtol=1e-5, atol=1e-6)

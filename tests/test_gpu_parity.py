@@ -146,3 +146,64 @@ def test_errors(ctx):
         ctx.render(0, 8, 1, 5)
     with pytest.raises(api.PtError):
         ctx.render(8, 8, 0, 5)
+
+
+def _cone_scene(order):
+    b = scenes.SceneBuilder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    for what in order:
+        if what == "cone":
+            b.cone((0, 0, 0), 2.0, 1.0, m)
+        elif what == "low":
+            b.xz_rect(-5, 5, -5, 5, 2.25, m)   # between the cone's real root (2.5) and mirror root (3.5) along the test ray
+        elif what == "high":
+            b.xz_rect(-5, 5, -5, 5, 3.0, m)    # beyond the mirror root
+        elif what == "pad":
+            for k in range(6):
+                b.sphere((20 + 3 * k, 0, 0), 1.0, m)
+    b.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    return b
+
+
+@pytest.mark.parametrize("order", [("cone", "low"), ("low", "cone"), ("cone", "high"), ("high", "cone"), ("pad", "low", "cone", "high"),
+                                   ("pad", "cone", "low"), ("low", "pad", "cone", "pad"), ("cone", "pad", "low", "pad")])
+def test_cone_list_order_dependence(ctx, order):
+    """A steep ray from below through a cone: the reference's answer depends on what EARLIER list entries hit
+    (cone.h:117-122 tries the larger root first).  The BVH path must reproduce it for every list order."""
+    b = _cone_scene(order)
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    rng = np.random.Generator(np.random.PCG64(9))
+    o = np.concatenate([[[0.25, -1, 0]], (rng.random((4000, 3), dtype=np.float32) * [2, 1, 2] - [1, 2, 1])]).astype(np.float32)
+    d = np.concatenate([[[0, 1, 0]], (rng.random((4000, 3), dtype=np.float32) * [1, 1, 1] - [0.5, 0, 0.5])]).astype(np.float32)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d)
+    ok = ref["nan_flag"] == 0
+    bad = util.hits_equal(got, ref) & ok
+    assert not bad.any(), (order, bad.sum(), np.flatnonzero(bad)[:4])
+    lin = ctx.trace(o, d, mode=api.TRACE_LINEAR)
+    assert not (util.hits_equal(lin, ref) & ok).any()
+
+
+def test_cone_field_exercises_the_exact_path(ctx):
+    """Many cones, many steep upward rays: the order-dependent cases occur in numbers and stay bit-exact."""
+    rng = np.random.Generator(np.random.PCG64(4))
+    b = scenes.SceneBuilder()
+    mats = [b.lambertian((0.5, 0.5, 0.5)), b.metal((0.8, 0.8, 0.8), 0.1)]
+    for k in range(300):
+        c = rng.random(3) * [20, 6, 20]
+        if k % 3 == 0:
+            b.sphere(c, 0.4 + rng.random() * 0.5, mats[k % 2])
+        else:
+            b.cone(c, 0.6 + rng.random() * 1.5, 0.3 + rng.random() * 0.7, mats[k % 2])
+    b.camera((10, 3, -15), (10, 3, 10), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    n = 60000
+    o = (rng.random((n, 3), dtype=np.float32) * [20, 1, 20] - [0, 2, 0]).astype(np.float32)
+    d = (rng.random((n, 3), dtype=np.float32) * [0.6, 1, 0.6] - [0.3, 0, 0.3] + [0, 0.2, 0]).astype(np.float32)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d)
+    ok = ref["nan_flag"] == 0
+    assert not (util.hits_equal(got, ref) & ok).any()
+    assert (got["flags"] & 1).sum() > 10  # the list-order scan did resolve some rays

@@ -1,0 +1,180 @@
+"""CPU tests of the host side: the shared library loads and exports the declared C ABI, and the
+host logic behind it (camera, BVH builder, flattening checks, film finish, sharding) is correct.
+No compute call is made: there is no GPU here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pt_oracle as O
+from pathtracer_amd import api, distributed, scenes
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z_]+)\s*\(", hdr))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    L = api.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert "gfx950" in api.version()
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(api.PtCamera) == 22 * 4
+    assert api.HIT_DTYPE.itemsize == 40 and api.NODE_DTYPE.itemsize == 64
+    assert C.sizeof(api.PtRenderParams) == 40 and C.sizeof(api.PtStats) == 88
+
+
+def test_context_create_fails_cleanly_without_a_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.PtError):  # status, not exit(99) as the reference's checkCudaErrors
+        api.Context(0)
+
+
+@pytest.mark.parametrize("builder", [scenes.default_scene, scenes.cornell_scene, scenes.random_spheres_scene])
+def test_camera_bit_exact_against_oracle(builder):
+    b = builder()
+    lib_cam = api.camera_fields(api.camera_look_at(*b.camera_args))
+    orc_cam = util.oracle_scene(b).camera_fields()
+    for k, ok in (("origin", "origin"), ("lower_left_corner", "lower_left"), ("horizontal", "horizontal"), ("vertical", "vertical"),
+                  ("u", "u"), ("v", "v"), ("w", "w")):
+        assert np.array_equal(lib_cam[k].view(np.uint32), orc_cam[ok].view(np.uint32)), k
+    assert lib_cam["lens_radius"] == orc_cam["lens_radius"]
+
+
+def _check_tree(desc, nodes, order, leaf_max=4):
+    n = desc.c.n_prims
+    assert sorted(order.tolist()) == list(range(n))  # every object in exactly one leaf slot
+    seen = np.zeros(n, bool)
+    pp, pt = desc.prim_param, desc.prim_type
+
+    def prim_bounds(i):
+        q, t = pp[i], pt[i]
+        if t == api.SPHERE:
+            r = abs(q[3]); return q[:3] - r, q[:3] + r
+        if t in (api.CONE, api.CYLINDER):
+            r = abs(q[4]); return np.array([q[0] - r, q[1], q[2] - r]), np.array([q[0] + r, q[1] + q[3], q[2] + r])
+        ax = {api.XY_RECT: (0, 1, 2), api.XZ_RECT: (0, 2, 1), api.YZ_RECT: (1, 2, 0)}[t]
+        lo, hi = np.zeros(3), np.zeros(3)
+        lo[ax[0]], hi[ax[0]], lo[ax[1]], hi[ax[1]] = q[0], q[1], q[2], q[3]
+        lo[ax[2]], hi[ax[2]] = q[4] - 1e-4, q[4] + 1e-4
+        return lo, hi
+
+    def walk(ref, lo, hi, depth):
+        if ref < 0:
+            r = ~ref
+            first, count = r >> 3, (r & 7) + 1
+            assert count <= leaf_max
+            for s in range(first, first + count):
+                i = order[s]
+                assert not seen[i]
+                seen[i] = True
+                plo, phi = prim_bounds(i)
+                assert (plo >= lo - 1e-6).all() and (phi <= hi + 1e-6).all()  # the (padded) node box encloses the object
+            return depth
+        nd = nodes[ref]
+        for clo, chi in ((nd["lo0"], nd["hi0"]), (nd["lo1"], nd["hi1"])):
+            if np.isfinite(clo).all():
+                assert (clo >= lo - 1e-6).all() and (chi <= hi + 1e-6).all()  # children inside the parent
+        d0 = walk(int(nd["c0"]), nd["lo0"], nd["hi0"], depth + 1)
+        d1 = walk(int(nd["c1"]), nd["lo1"], nd["hi1"], depth + 1) if np.isfinite(nd["lo1"]).all() else depth
+        return max(d0, d1)
+
+    inf = np.full(3, np.inf)
+    depth = walk(0, -inf, inf, 0)
+    assert seen.all()
+    return depth
+
+
+@pytest.mark.parametrize("builder", [scenes.default_scene, scenes.cornell_scene, scenes.random_spheres_scene,
+                                     lambda: scenes.mixed_scene(n=3000, seed=5, extent=30.0, n_materials=32)])
+def test_bvh_invariants(builder):
+    d = builder().desc()
+    nodes, order, max_depth = api.bvh_build_host(d)
+    depth = _check_tree(d, nodes, order)
+    assert depth == max_depth and max_depth <= 64
+    if d.c.n_prims > 4:
+        assert len(nodes) >= d.c.n_prims // 4 - 1
+
+
+def test_bvh_degenerate_inputs():
+    b = scenes.SceneBuilder()
+    m = b.lambertian((1, 1, 1))
+    for _ in range(37):
+        b.sphere((1, 2, 3), 0.5, m)  # coincident centroids: SAH has nothing to cut, the median split must terminate
+    b.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    d = b.desc()
+    nodes, order, max_depth = api.bvh_build_host(d)
+    _check_tree(d, nodes, order)
+    one = scenes.SceneBuilder()
+    one.sphere((0, 0, 0), 1, one.lambertian((1, 1, 1)))
+    one.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    nodes, order, max_depth = api.bvh_build_host(one.desc())
+    assert len(nodes) == 1 and max_depth == 1 and list(order) == [0] and not np.isfinite(nodes[0]["lo1"]).any()
+
+
+def test_bad_scenes_are_rejected_not_crashed():
+    b = scenes.default_scene()
+    a = b.arrays()
+    cam = api.camera_look_at(*b.camera_args)
+    bad_mat = api.SceneDesc(a["prim_type"], a["prim_param"], np.array([0, 1, 9], np.uint32), a["mat_type"], a["mat_param"], cam)
+    with pytest.raises(api.PtError):  # the reference indexes materials[material_index] unchecked (sphere.h:71)
+        api.bvh_build_host(bad_mat)
+    bad_tag = api.SceneDesc(np.array([0, 0, 7], np.uint8), a["prim_param"], a["prim_material"], a["mat_type"], a["mat_param"], cam)
+    with pytest.raises(api.PtError):
+        api.bvh_build_host(bad_tag)
+    nan = a["prim_param"].copy()
+    nan[1, 0] = np.nan
+    with pytest.raises(api.PtError):
+        api.bvh_build_host(api.SceneDesc(a["prim_type"], nan, a["prim_material"], a["mat_type"], a["mat_param"], cam))
+    with pytest.raises(ValueError):
+        scenes.SceneBuilder().sphere((0, 0, 0), 1, 0)  # material must exist before the object that uses it
+    with pytest.raises(ValueError):
+        scenes.SceneBuilder().desc()  # no camera
+
+
+def test_metal_fuzz_clamp_and_cylinder_argument_order():
+    b = scenes.SceneBuilder()
+    m = b.metal((1, 1, 1), 3.0)
+    assert b.arrays()["mat_param"][m, 3] == 1.0  # material.h:150
+    c = scenes.cornell_scene().arrays()
+    cyl = c["prim_param"][c["prim_type"] == api.CYLINDER][0]
+    assert cyl[3] == 200 and cyl[4] == 64  # scene.h:85 passes (center, 200, 64): height 200, radius 64
+
+
+def test_film_finalize_bit_exact_against_oracle():
+    rng = np.random.Generator(np.random.PCG64(1))
+    img = (rng.random((9, 13, 3), dtype=np.float32) * 40).astype(np.float32)
+    img[0, 0] = [0, 1e-9, 1e9]
+    g1, q1 = api.film_finalize(img, 17)
+    g2, q2 = O.finalize(img, 17)
+    assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(q1, q2)
+    assert q1.max() == 255 and q1.min() == 0
+    # rows are written top-down from j = H-1 (main.cu:194): the first 8-bit row is the last float row
+    assert np.array_equal(q1[0], (256 * np.clip(g1[-1], 0, 0.999)).astype(np.int32).astype(np.uint8))
+
+
+def test_shards():
+    assert [distributed.weak_shard(r, 4, 64) for r in range(4)] == [(0, 64), (64, 64), (128, 64), (192, 64)]
+    cuts = [distributed.strong_shard(r, 8, 67) for r in range(8)]
+    assert sum(n for _, n in cuts) == 67 and cuts[0][0] == 0
+    assert all(cuts[k][0] + cuts[k][1] == cuts[k + 1][0] for k in range(7))
+    assert max(n for _, n in cuts) - min(n for _, n in cuts) <= 1
+    with pytest.raises(ValueError):
+        distributed.weak_shard(4, 4, 8)
+
+
+def test_random_spheres_scene_is_the_named_workload():
+    a = scenes.random_spheres_scene().arrays()
+    assert len(a["prim_type"]) == 485 and (a["prim_type"] == api.SPHERE).all()
+    kinds = a["mat_type"][a["prim_material"]]
+    assert (kinds == api.LAMBERTIAN).sum() > 350 and (kinds == api.METAL).sum() > 40 and (kinds == api.DIELECTRIC).sum() > 10
