@@ -1,0 +1,187 @@
+// pt_host.h -- the host-side session behind the scene API headers.
+//
+// In the reference every host object has a device twin made by a <<<1,1>>> kernel doing a
+// device-side `new` at create_*_on_gpu() time (sphere.h:31-34, material.h:125-128, ...).  Here the
+// same calls take a SNAPSHOT of the object's parameters into this registry (same moment, same
+// ordering contract: materials before the objects that use them, objects before
+// hittable_list::copy_list_to_gpu).  A world and a camera become device data only when they are
+// first rendered: pt_host::render() flattens the snapshot, uploads it through the C ABI
+// (pt_scene_upload) and runs the wavefront integrator (pt_render).
+#ifndef PT_HOST_SESSION_H
+#define PT_HOST_SESSION_H
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "vec3.h"
+
+namespace pt_host {
+
+struct scene_error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct Options {
+    int max_depth = 5;         // ray_color's depth argument in the reference (main.cu:93)
+    uint64_t seed = 1984;      // main.cu:34
+    int device = 0;
+    // The reference's file loaders parse a cone's / cylinder's `center` and then drop it, so those
+    // objects always sit at the origin (cone.h:58-61,74; cylinder.h:57-60,73).  false reproduces that.
+    bool honor_cone_cylinder_center = false;
+};
+
+struct Flat { // what pt_scene_desc points into
+    std::vector<uint8_t> prim_type, mat_type;
+    std::vector<float> prim_param, mat_param;
+    std::vector<uint32_t> prim_material;
+};
+
+class Session {
+public:
+    static Session &get()
+    {
+        static Session s;
+        return s;
+    }
+    Options options;
+
+    // create_material_on_gpu(): snapshot; returns the material's index
+    int add_material(uint8_t tag, float a, float b, float c, float d)
+    {
+        mat_tag_.push_back(tag);
+        const float p[4] = {a, b, c, d};
+        mat_par_.insert(mat_par_.end(), p, p + 4);
+        return (int)mat_tag_.size() - 1;
+    }
+    // create_hittable_on_gpu(): snapshot; returns the object's slot
+    int add_object(uint8_t tag, const float p[6], int material_index)
+    {
+        if (material_index < 0 || material_index >= (int)mat_tag_.size())
+            throw scene_error("create_hittable_on_gpu(): the object's material has not been created on the GPU yet");
+        obj_tag_.push_back(tag);
+        obj_par_.insert(obj_par_.end(), p, p + 6);
+        obj_mat_.push_back((uint32_t)material_index);
+        return (int)obj_tag_.size() - 1;
+    }
+    // hittable_list::copy_list_to_gpu(): the world is the listed slots, in list order
+    void set_world(const void *handle, const std::vector<int> &slots)
+    {
+        for (int s : slots)
+            if (s < 0 || s >= (int)obj_tag_.size()) throw scene_error("copy_list_to_gpu(): a listed object has not been created on the GPU yet");
+        worlds_[handle] = slots;
+        uploaded_world_ = nullptr;
+    }
+    void drop_world(const void *handle)
+    {
+        worlds_.erase(handle);
+        if (uploaded_world_ == handle) uploaded_world_ = nullptr;
+    }
+    void set_camera(const void *handle, const pt_camera &c)
+    {
+        cameras_[handle] = c;
+        uploaded_camera_ = nullptr;
+    }
+    void drop_camera(const void *handle)
+    {
+        cameras_.erase(handle);
+        if (uploaded_camera_ == handle) uploaded_camera_ = nullptr;
+    }
+
+    // The flattened arrays of a world, as pt_scene_upload would receive them (no GPU involved).
+    Flat flatten(const void *world_handle) const
+    {
+        auto it = worlds_.find(world_handle);
+        if (it == worlds_.end()) throw scene_error("unknown world handle: call create_hittable_on_gpu() and copy_list_to_gpu() first");
+        Flat f;
+        // every material created so far, in creation order: a positional `material = N` in scene.txt
+        // refers to that order (scene.h:216-237), and the object snapshots hold those indices
+        f.mat_type = mat_tag_;
+        f.mat_param = mat_par_;
+        for (int s : it->second) {
+            f.prim_type.push_back(obj_tag_[s]);
+            f.prim_param.insert(f.prim_param.end(), obj_par_.begin() + 6 * (size_t)s, obj_par_.begin() + 6 * (size_t)s + 6);
+            f.prim_material.push_back(obj_mat_[s]);
+        }
+        return f;
+    }
+    const pt_camera &camera(const void *handle) const
+    {
+        auto it = cameras_.find(handle);
+        if (it == cameras_.end()) throw scene_error("unknown camera handle: call create_camera_on_gpu() first");
+        return it->second;
+    }
+
+    // Linear sums of `spp` samples per pixel (pt_render); uploads the world/camera pair if it changed.
+    void render_sum(const void *world_handle, const void *camera_handle, const float background[3], int width, int height, int spp,
+                    std::vector<float> &sum, pt_stats *stats = nullptr)
+    {
+        ensure_context();
+        if (uploaded_world_ != world_handle || uploaded_camera_ != camera_handle || std::memcmp(uploaded_bg_, background, 12) != 0) {
+            Flat f = flatten(world_handle);
+            pt_scene_desc d{};
+            d.n_prims = (uint32_t)f.prim_type.size();
+            d.prim_type = f.prim_type.data();
+            d.prim_param = f.prim_param.data();
+            d.prim_material = f.prim_material.data();
+            d.n_materials = (uint32_t)f.mat_type.size();
+            d.mat_type = f.mat_type.data();
+            d.mat_param = f.mat_param.data();
+            d.camera = camera(camera_handle);
+            std::memcpy(d.background, background, 12);
+            check(pt_scene_upload(ctx_, &d), "pt_scene_upload");
+            uploaded_world_ = world_handle;
+            uploaded_camera_ = camera_handle;
+            std::memcpy(uploaded_bg_, background, 12);
+        }
+        pt_render_params p{};
+        p.width = width;
+        p.height = height;
+        p.spp = (uint32_t)spp;
+        p.max_depth = options.max_depth;
+        p.seed = options.seed;
+        sum.assign((size_t)width * height * 3, 0.0f);
+        check(pt_render(ctx_, &p, sum.data(), stats), "pt_render");
+    }
+
+    // Forgets every snapshot (the scene on the GPU stays until the next upload).
+    void reset()
+    {
+        mat_tag_.clear(); obj_tag_.clear(); mat_par_.clear(); obj_par_.clear(); obj_mat_.clear();
+        worlds_.clear(); cameras_.clear();
+        uploaded_world_ = uploaded_camera_ = nullptr;
+    }
+
+    ~Session()
+    {
+        if (ctx_) pt_context_destroy(ctx_);
+    }
+
+private:
+    Session() {}
+    void ensure_context()
+    {
+        if (!ctx_ && pt_context_create(options.device, &ctx_) != PT_OK)
+            throw scene_error("pt_context_create failed: no usable GPU (this renderer has no CPU fallback)");
+    }
+    void check(pt_status st, const char *what)
+    {
+        if (st != PT_OK) throw scene_error(std::string(what) + ": " + pt_last_error(ctx_));
+    }
+    std::vector<uint8_t> mat_tag_, obj_tag_;
+    std::vector<float> mat_par_, obj_par_;
+    std::vector<uint32_t> obj_mat_;
+    std::map<const void *, std::vector<int>> worlds_;
+    std::map<const void *, pt_camera> cameras_;
+    pt_context *ctx_ = nullptr;
+    const void *uploaded_world_ = nullptr, *uploaded_camera_ = nullptr;
+    float uploaded_bg_[3] = {0, 0, 0};
+};
+
+inline Options &options() { return Session::get().options; }
+
+} // namespace pt_host
+#endif

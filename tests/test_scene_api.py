@@ -1,0 +1,176 @@
+"""The C++ scene API above the C ABI (pathtracer_amd/host): scene definitions written against the reference's
+class surface flatten to exactly the arrays the Python scenes produce; the scene.txt loader follows the
+reference's grammar, reproduces its dropped cone/cylinder centre and fails cleanly where the reference hangs."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "pathtracer_amd", "host")
+SAMPLE = os.path.join(ROOT, "tests", "golden", "scene_sample.txt")
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(HOST, "libpt_host_scenes.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", HOST])
+    L = C.CDLL(so)
+    L.pth_error.restype = C.c_char_p
+    L.pth_copy.argtypes = [C.c_void_p] * 5 + [C.POINTER(api.PtCamera), C.c_void_p]
+    L.pth_open_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pth_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_ulonglong)]
+    return L
+
+
+def _arrays(L):
+    n, m = C.c_int(), C.c_int()
+    assert L.pth_counts(C.byref(n), C.byref(m)) == 0
+    pt, pp, pm = np.zeros(n.value, np.uint8), np.zeros((n.value, 6), np.float32), np.zeros(n.value, np.uint32)
+    mt, mp = np.zeros(m.value, np.uint8), np.zeros((m.value, 4), np.float32)
+    cam, bg = api.PtCamera(), (C.c_float * 3)()
+    assert L.pth_copy(pt.ctypes.data, pp.ctypes.data, pm.ctypes.data, mt.ctypes.data, mp.ctypes.data, C.byref(cam), bg) == 0
+    return dict(prim_type=pt, prim_param=pp, prim_material=pm, mat_type=mt, mat_param=mp), cam, tuple(bg)
+
+
+def _same(a, b):
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+
+
+def _same_camera(cam, args):
+    ref = api.camera_fields(api.camera_look_at(*args))
+    got = api.camera_fields(cam)
+    for k in ref:
+        assert np.array_equal(np.asarray(got[k]).view(np.uint32), np.asarray(ref[k]).view(np.uint32)), k
+
+
+@pytest.mark.parametrize("which,builder", [(0, scenes.default_scene), (1, scenes.cornell_scene)])
+def test_builtin_scenes_flatten_identically(H, which, builder):
+    assert H.pth_open_builtin(which) == 0, H.pth_error()
+    arrays, cam, bg = _arrays(H)
+    b = builder()
+    _same(arrays, b.arrays())
+    _same_camera(cam, b.camera_args)
+    assert bg == b.background
+    H.pth_close()
+
+
+def _sample_builder(honor_center):
+    b = scenes.SceneBuilder(background=(0.7, 0.8, 1.0))
+    m = [b.lambertian((0.5, 0.5, 0.5)), b.metal((0.8, 0.6, 0.2), 0.25), b.dielectric(1.5), b.diffuse_light((6, 6, 6)), b.lambertian((0.1, 0.2, 0.7))]
+    b.sphere((0, -1000, 0), 1000, m[0])
+    b.sphere((-3, 1, 0), 1, m[2])
+    c = (5, 0, 5) if honor_center else (0, 0, 0)  # cone.h:58-61,74 / cylinder.h:57-60,73 drop the parsed centre
+    b.cylinder2(c, 2.5, 0.75, m[1])
+    b.cone(c, 3, 1.25, m[4])
+    b.xy_rect(2, 4, 0.5, 2.5, -2, m[3])
+    b.xz_rect(-2, 2, -2, 2, 5, m[3])
+    b.yz_rect(0, 2, -1, 1, -5, m[1])
+    b.camera((13, 4, 9), (0, 1, 0), (0, 1, 0), 30.0, np.float32(160) / np.float32(90), 0.05, 12.0)
+    return b
+
+
+@pytest.mark.parametrize("honor", [0, 1])
+def test_scene_file_loader(H, honor):
+    w, h, s = C.c_int(), C.c_int(), C.c_int()
+    assert H.pth_open_file(SAMPLE.encode(), honor, w, h, s) == 0, H.pth_error()
+    assert (w.value, h.value, s.value) == (160, 90, 4)
+    arrays, cam, bg = _arrays(H)
+    b = _sample_builder(bool(honor))
+    _same(arrays, b.arrays())
+    _same_camera(cam, b.camera_args)
+    assert np.allclose(bg, (0.7, 0.8, 1.0))
+    H.pth_close()
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda t: t[: t.index("Objects")], "ended"),                           # no Objects / END: the reference spins forever
+    (lambda t: t.replace("END\n", ""), "ended"),
+    (lambda t: t.replace("material = 4", "material = 9"), "material 9"),     # unchecked index in the reference (sphere.h:71)
+    (lambda t: t.replace("radius = 1000", "radius = big"), "malformed"),
+    (lambda t: t.replace("Scene\n", ""), "Wrong file format"),  # main.cu:151-154
+])
+def test_scene_file_errors_are_clean(H, tmp_path, mutate, needle):
+    p = tmp_path / "scene.txt"
+    p.write_text(mutate(open(SAMPLE).read()))
+    assert H.pth_open_file(str(p).encode(), 0, None, None, None) == -1
+    assert needle in H.pth_error().decode()
+
+
+def test_ordering_contract_is_checked(H):
+    assert H.pth_ordering_violation() == 1  # object created before its material: refused, where the reference dereferences NULL
+
+
+def test_reference_style_scene_definition_compiles_without_cuda(tmp_path):
+    """A scene definition written the reference's way (constructors, create_*_on_gpu, public fields, d_this)
+    compiles against pathtracer_amd/host with plain g++ and no GPU toolkit."""
+    src = tmp_path / "user_scene.cpp"
+    src.write_text(r'''
+#include "scene.h"
+#include "render.h"
+int build(std::vector<hittable*>& hitables, hittable_list*& world, camera*& cam) {
+    auto ground_material = new lambertian(color(0.5, 0.5, 0.5));
+    ground_material->create_material_on_gpu();
+    auto ground = new sphere(point3(0, -1000, 0), 1000, ground_material);
+    hitables.push_back(ground);
+    auto glass = new dielectric(1.5f);  glass->create_material_on_gpu();
+    auto mirror = new metal(color(0.7f, 0.6f, 0.5f), 0.0f);  mirror->create_material_on_gpu();
+    hitables.push_back(new sphere(point3(0, 1, 0), 1.0f, glass));
+    hitables.push_back(new cone(point3(2, 0, 2), 2.0f, 1.0f, mirror));
+    hitables.push_back(new cylinder2(point3(-2, 0, 2), 200, 64, mirror));
+    hitables.push_back(new yz_rect(0, 555, 0, 555, 555, ground_material));
+    hittable** list = new hittable * [hitables.size()];
+    for (int i = 0; i < hitables.size(); i++) { list[i] = hitables[i]; list[i]->create_hittable_on_gpu(); }
+    world = new hittable_list(list, hitables.size());
+    world->create_hittable_on_gpu();
+    world->copy_list_to_gpu();
+    cam = new camera(point3(26, 3, 6), point3(0, 2, 0), vec3(0,1,0), 20.0, 16.0f / 9.0f, 0.1, 10.0);
+    cam->create_camera_on_gpu();
+    aabb box; ground->bounding_box(0, 1, box);
+    return cam->d_this != NULL && world->d_this != NULL && ground->material_ptr == ground_material && ground->radius == 1000 && box.max().y() == 0;
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wno-sign-compare", "-I", HOST, str(src)])
+
+
+@pytest.mark.gpu
+def test_cpp_path_renders_what_the_python_path_renders(H, ctx):
+    assert H.pth_open_file(SAMPLE.encode(), 0, None, None, None) == 0, H.pth_error()
+    fb = np.zeros((90, 160, 3), np.float32)
+    rays = C.c_ulonglong()
+    assert H.pth_render(160, 90, 4, 5, fb.ctypes.data, rays) == 0, H.pth_error()
+    b = _sample_builder(False)
+    ctx.upload(b.desc())
+    img, st = ctx.render(160, 90, 4, 5)
+    gamma, _ = api.film_finalize(img, 4)
+    assert rays.value == st["rays"]
+    assert np.array_equal(fb.view(np.uint32), gamma.view(np.uint32))
+    H.pth_close()
+
+
+@pytest.mark.gpu
+def test_program_writes_the_image(tmp_path):
+    exe = os.path.join(HOST, "pathtracer")
+    (tmp_path / "scene.txt").write_text(open(SAMPLE).read())
+    r = subprocess.run([exe, "--pfm", "out.pfm"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Rendering a 160x90 image in 8x8 blocks." in r.stderr and "Cuda computation took" in r.stderr and "Image write took" in r.stderr
+    bmp = (tmp_path / "image.bmp").read_bytes()
+    assert bmp[:2] == b"BM" and len(bmp) == 54 + 160 * 90 * 3
+    assert int.from_bytes(bmp[18:22], "little") == 160 and int.from_bytes(bmp[22:26], "little") == 90
+    pix = np.frombuffer(bmp[54:], np.uint8).reshape(90, 160, 3)  # bottom-up BGR
+    assert pix.mean() > 20 and pix.std() > 5
+    pfm = (tmp_path / "out.pfm").read_bytes()
+    head = b"PF\n160 90\n-1.0\n"
+    assert pfm.startswith(head)
+    fb = np.frombuffer(pfm[len(head):], np.float32).reshape(90, 160, 3)
+    q = (256 * np.clip(fb, 0, 0.999)).astype(np.int32).astype(np.uint8)
+    assert np.array_equal(q[:, :, ::-1], pix)  # the BMP is the quantised frame buffer
+    missing = subprocess.run([exe, "--spp", "1"], cwd=tmp_path / "..", capture_output=True, text=True, timeout=120)  # no scene.txt: default scene
+    assert missing.returncode == 0 and "Rendering a 1200x902 image" in missing.stderr
