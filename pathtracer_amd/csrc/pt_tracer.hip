@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -119,9 +120,41 @@ PT_DI bool box_test(const float *lo, const float *hi, const BoxRay &b, float t_m
 // list entry already produced a hit nearer than the larger root.  Such a candidate is parked and
 // decided after the traversal when that is possible from what the traversal knows; otherwise the
 // ray is flagged and re-resolved by linear_nearest().
-template <bool COUNT>
-PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float t_max, uint32_t *stack /* [sp*PT_BLOCK] */,
-                            bool &need_exact, uint32_t &n_box, uint32_t &n_prim)
+// Where the traversal reads nodes and objects from.  GlobalSrc: the 64-B / 32-B records in HBM (cached
+// in L2 / Infinity Cache).  LdsSrc: a copy in the workgroup's LDS for scenes that fit, stored as float4
+// PLANES (quarter j of every node in plane j) so that the 64 lanes of one ds_read_b128 spread over all
+// sixteen 16-byte bank slots instead of the four a 64-byte-strided record array would use.
+struct GlobalSrc {
+    const BvhNode *nodes;
+    const PrimRec *prims;
+    __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
+    {
+        const float4 *np = reinterpret_cast<const float4 *>(nodes + i);
+        a = np[0]; b = np[1]; c = np[2]; d = np[3];
+    }
+    __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
+    {
+        const float4 *pp = reinterpret_cast<const float4 *>(prims + slot);
+        w0 = pp[0]; w1 = pp[1];
+    }
+};
+struct LdsSrc {
+    const float4 *nodes; // 4 planes of n_nodes
+    const float4 *prims; // 2 planes of n_prims
+    uint32_t n_nodes, n_prims;
+    __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
+    {
+        a = nodes[i]; b = nodes[n_nodes + i]; c = nodes[2 * n_nodes + i]; d = nodes[3 * n_nodes + i];
+    }
+    __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
+    {
+        w0 = prims[slot]; w1 = prims[n_prims + slot];
+    }
+};
+
+template <bool COUNT, int STRIDE, class Src>
+PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
+                            uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim)
 {
     BoxRay br;
     br.ox = r.o.x; br.oy = r.o.y; br.oz = r.o.z;
@@ -136,11 +169,11 @@ PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float
 
     uint32_t sp = 0;
     int32_t cur = 0; // root
-    const uint32_t cap = sc.stack_cap;
+    const uint32_t cap = stack_cap;
     for (;;) {
         if (cur >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
-            float4 a = np[0], b = np[1], c = np[2], d = np[3];
+            float4 a, b, c, d;
+            src.node(cur, a, b, c, d);
             float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z};
             float lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
             int32_t c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
@@ -151,7 +184,7 @@ PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
                 int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                if (sp < cap) stack[(sp++) * PT_BLOCK] = (uint32_t)farc;
+                if (sp < cap) stack[(sp++) * STRIDE] = (uint32_t)farc;
                 else need_exact = true; // cannot happen: cap >= tree depth; never corrupt, re-resolve instead
                 cur = nearc;
                 continue;
@@ -163,8 +196,8 @@ PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float
             uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t slot = first + k;
-                const float4 *pp = reinterpret_cast<const float4 *>(sc.prims + slot);
-                float4 w0 = pp[0], w1 = pp[1];
+                float4 w0, w1;
+                src.prim(slot, w0, w1);
                 PrimRec q;
                 q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
                 q.meta = __float_as_uint(w1.z);
@@ -213,7 +246,7 @@ PT_DI HitResult bvh_nearest(const SceneDev &sc, const Ray &r, float t_min, float
             }
         }
         if (sp == 0) break;
-        cur = (int32_t)stack[(--sp) * PT_BLOCK];
+        cur = (int32_t)stack[(--sp) * STRIDE];
     }
 
     if (n_pend > 1) need_exact = true;
@@ -280,7 +313,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
         } else {
             bool need_exact;
             uint32_t nb = 0, np = 0;
-            h = bvh_nearest<false>(sc, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+            GlobalSrc src{sc.nodes, sc.prims};
+            h = bvh_nearest<false, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
             arr = sc.prims;
             if (need_exact) {
                 h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
@@ -347,14 +381,35 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(SceneDev sc, PassDev ps, Pa
     }
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void k_intersect(SceneDev sc, PathPlanes st, uint2 *__restrict__ hits,
-                                                        const uint32_t *__restrict__ n_ptr, Counters *cnt)
+#define PT_ISECT_LDS_BLOCK 1024 // workgroup size of the LDS-resident variant: two of them fill a CU's 32 wave slots
+
+// Nearest hit for every queued ray.  LDS = true: the workgroup first copies the whole tree and object
+// array into LDS (scenes up to a few thousand objects) and traverses from there.
+template <bool COUNT, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st, uint2 *__restrict__ hits,
+                                                     const uint32_t *__restrict__ n_ptr, Counters *cnt)
 {
-    extern __shared__ uint32_t s_stack[];
+    extern __shared__ float4 s_mem[];
     const uint32_t n = *n_ptr;
+    if (blockIdx.x * BLOCK >= n) return; // uniform per workgroup: nothing queued for it
+    uint32_t *s_stack;
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims};
+    if (LDS) {
+        float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
+        s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
+        const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
+        for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) s_nodes[(i & 3u) * sc.n_nodes + (i >> 2)] = gn[i];
+        for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
+        lsrc.nodes = s_nodes;
+        lsrc.prims = s_prims;
+        __syncthreads();
+    } else {
+        s_stack = reinterpret_cast<uint32_t *>(s_mem);
+    }
+    GlobalSrc gsrc{sc.nodes, sc.prims};
     uint32_t nb = 0, np = 0, nf = 0;
-    for (uint32_t base = blockIdx.x * PT_BLOCK; base < n; base += gridDim.x * PT_BLOCK) {
+    const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
+    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
         uint32_t i = base + threadIdx.x;
         if (i >= n) continue;
         float4 A = st.A[i], B = st.B[i];
@@ -362,13 +417,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_intersect(SceneDev sc, PathPlanes 
         r.o = V(A.x, A.y, A.z);
         r.d = V(B.x, B.y, B.z);
         bool need_exact;
-        HitResult h = bvh_nearest<COUNT>(sc, r, 0.001f /* main.cu:54 */, PT_FLT_MAX /* commons.h:11 */, s_stack + threadIdx.x,
-                                         need_exact, nb, np);
+        HitResult h;
+        if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+        else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
         uint32_t slot = h.slot;
         if (need_exact) {
-            h = linear_nearest(sc.prims_list, sc.n_prims, r, 0.001f, PT_FLT_MAX);
-            // translate the list index to a leaf slot via the record's own id: list records carry their slot in .id? no:
-            // list-order records keep id = list index, so flag the slot as "list order" with the top bit.
+            // resolved on the list-order records; the top bit of the slot says which array it indexes
+            h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             slot = h.slot == PT_NO_PRIM ? PT_NO_PRIM : (h.slot | 0x80000000u);
             nf++;
         }
@@ -536,6 +591,7 @@ struct pt_context {
     PrimRec *d_prims = nullptr, *d_prims_list = nullptr;
     float4 *d_mats = nullptr;
     uint32_t max_depth_tree = 0;
+    bool lds_scene = true; // traverse small scenes from LDS (PT_RENDER_NO_LDS_SCENE turns it off for A/B runs)
 
     // integrator workspace (grown on demand, kept across calls)
     size_t cap_paths = 0;
@@ -751,6 +807,33 @@ static uint32_t grid_for(const pt_context *ctx, size_t n)
     return (uint32_t)std::max<size_t>(1, std::min(blocks, cap));
 }
 
+// LDS bytes of the resident-scene variant; 0 when the scene does not fit beside the traversal stack.
+static size_t lds_scene_bytes(const pt_context *ctx)
+{
+    const SceneDev &sc = ctx->sc;
+    size_t b = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32 + (size_t)sc.stack_cap * PT_ISECT_LDS_BLOCK * 4;
+    return b <= 80 * 1024 ? b : 0; // two workgroups per CU must fit in 160 KB
+}
+
+static void launch_intersect(pt_context *ctx, hipStream_t stream, const PathPlanes &cur, const uint32_t *n_ptr, size_t max_paths, bool count)
+{
+    const size_t lds_res = ctx->lds_scene ? lds_scene_bytes(ctx) : 0;
+    if (lds_res) {
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min((max_paths + PT_ISECT_LDS_BLOCK - 1) / PT_ISECT_LDS_BLOCK, (size_t)ctx->n_cu * 2));
+        if (count)
+            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+        else
+            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+    } else {
+        const uint32_t grid = grid_for(ctx, max_paths);
+        const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
+        if (count)
+            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+        else
+            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+    }
+}
+
 extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, const float *d_d, size_t n, float t_min,
                                           float t_max, int mode, pt_hit *d_out, void *stream_)
 {
@@ -876,7 +959,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
     ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
     ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
     ps.max_depth = pr->max_depth;
-    const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
+    ctx->lds_scene = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0;
     uint32_t n_passes = 0, n_isect = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
@@ -890,10 +973,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
         tm.end();
         for (int32_t b = 0; b < pr->max_depth; ++b) {
             tm.begin(1);
-            if (count)
-                hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, ctx->d_nactive + b, ctx->d_cnt);
-            else
-                hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, ctx->d_nactive + b, ctx->d_cnt);
+            launch_intersect(ctx, stream, cur, ctx->d_nactive + b, np, count);
             tm.end();
             ++n_isect;
             tm.begin(2);
