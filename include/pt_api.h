@@ -89,7 +89,8 @@ enum {
     PT_RENDER_STAGE_TIMES = 1u, /* time every kernel with events (slower; fills pt_stats.ms_*) */
     PT_RENDER_NO_SORT = 2u,     /* shade in queue order instead of material-sorted order */
     PT_RENDER_COUNT_TESTS = 4u, /* count box / object tests per ray (slower; fills pt_stats.box_tests / prim_tests) */
-    PT_RENDER_NO_LDS_SCENE = 8u /* traverse from global memory even when the scene would fit in LDS */
+    PT_RENDER_NO_LDS_SCENE = 8u, /* traverse from global memory even when the scene would fit in LDS */
+    PT_RENDER_SPLIT_KERNELS = 16u /* one launch per stage and bounce over global queues instead of the persistent-workgroup kernel */
 };
 
 typedef struct pt_stats {
@@ -98,9 +99,10 @@ typedef struct pt_stats {
     uint64_t box_tests, prim_tests; /* only with PT_RENDER_COUNT_TESTS */
     uint64_t exact_fallbacks;       /* rays resolved by the list-order scan */
     double ms_total;                /* device time of the whole call (events on the call's stream) */
-    double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES */
-    uint32_t launches_intersect;
+    double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES | PT_RENDER_SPLIT_KERNELS */
+    uint32_t launches_intersect; /* launches of the dominant kernel (k_intersect, or k_paths) */
     uint32_t passes;
+    double ms_paths; /* only with PT_RENDER_STAGE_TIMES: summed k_paths launch time */
 } pt_stats;
 
 typedef struct pt_context pt_context;

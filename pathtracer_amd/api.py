@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ER
 SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
 TRACE_BVH, TRACE_LINEAR = 0, 1
-RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE = 1, 2, 4, 8
+RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS = 1, 2, 4, 8, 16
 NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -60,7 +60,7 @@ class PtStats(C.Structure):
         ("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("box_tests", C.c_uint64), ("prim_tests", C.c_uint64),
         ("exact_fallbacks", C.c_uint64), ("ms_total", C.c_double), ("ms_raygen", C.c_double),
         ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
-        ("launches_intersect", C.c_uint32), ("passes", C.c_uint32),
+        ("launches_intersect", C.c_uint32), ("passes", C.c_uint32), ("ms_paths", C.c_double),
     ]
 
     def as_dict(self):

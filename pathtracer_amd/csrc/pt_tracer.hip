@@ -353,30 +353,37 @@ struct PassDev {
     int32_t max_depth;
 };
 
-// camera::get_ray (camera.h:88-96) with the jitter of main.cu:90-91.  Path id = s*n_pixels + pixel.
+// camera::get_ray (camera.h:88-96) with the jitter of main.cu:90-91 for one (pixel, absolute sample).
+PT_DI Ray camera_ray(const DeviceCamera &c, const PassDev &ps, uint32_t pixel, uint32_t sample_abs)
+{
+    uint32_t j = pixel / ps.width, i = pixel - j * ps.width;
+    Rng g;
+    g.pixel = pixel; g.sample = sample_abs; g.bounce = 0; g.block = 0; g.k0 = ps.k0; g.k1 = ps.k1;
+    float u4[4];
+    rng_block(g, u4);
+    float u = ((float)i + u4[0]) / (float)ps.width;   // main.cu:90
+    float v = ((float)j + u4[1]) / (float)ps.height;  // main.cu:91
+    v3 disk = random_in_unit_disk(g);
+    v3 rd = vscale(c.lens_radius, disk);                                             // camera.h:89
+    v3 offset = vadd(vscale(rd.x, V(c.u[0], c.u[1], c.u[2])), vscale(rd.y, V(c.v[0], c.v[1], c.v[2]))); // :90
+    v3 origin = V(c.origin[0], c.origin[1], c.origin[2]);
+    Ray r;
+    r.o = vadd(origin, offset);                                                      // camera.h:93
+    r.d = vsub(vsub(vadd(vadd(V(c.llc[0], c.llc[1], c.llc[2]), vscale(u, V(c.horizontal[0], c.horizontal[1], c.horizontal[2]))),
+                         vscale(v, V(c.vertical[0], c.vertical[1], c.vertical[2]))), origin), offset); // camera.h:94
+    return r;
+}
+
+// Path id = s*n_pixels + pixel.
 __global__ __launch_bounds__(PT_BLOCK) void k_raygen(SceneDev sc, PassDev ps, PathPlanes st, uint32_t *n_active)
 {
     const uint32_t total = ps.samples * ps.n_pixels;
     if (blockIdx.x == 0 && threadIdx.x == 0) n_active[0] = total;
     for (uint32_t id = blockIdx.x * PT_BLOCK + threadIdx.x; id < total; id += gridDim.x * PT_BLOCK) {
         uint32_t s = id / ps.n_pixels, pixel = id - s * ps.n_pixels;
-        uint32_t j = pixel / ps.width, i = pixel - j * ps.width;
-        Rng g;
-        g.pixel = pixel; g.sample = ps.sample_base + s; g.bounce = 0; g.block = 0; g.k0 = ps.k0; g.k1 = ps.k1;
-        float u4[4];
-        rng_block(g, u4);
-        float u = ((float)i + u4[0]) / (float)ps.width;   // main.cu:90
-        float v = ((float)j + u4[1]) / (float)ps.height;  // main.cu:91
-        v3 disk = random_in_unit_disk(g);
-        const DeviceCamera &c = sc.cam;
-        v3 rd = vscale(c.lens_radius, disk);                                             // camera.h:89
-        v3 offset = vadd(vscale(rd.x, V(c.u[0], c.u[1], c.u[2])), vscale(rd.y, V(c.v[0], c.v[1], c.v[2]))); // :90
-        v3 origin = V(c.origin[0], c.origin[1], c.origin[2]);
-        v3 o = vadd(origin, offset);                                                     // camera.h:93
-        v3 dir = vsub(vsub(vadd(vadd(V(c.llc[0], c.llc[1], c.llc[2]), vscale(u, V(c.horizontal[0], c.horizontal[1], c.horizontal[2]))),
-                                vscale(v, V(c.vertical[0], c.vertical[1], c.vertical[2]))), origin), offset); // camera.h:94
-        st.A[id] = make_float4(o.x, o.y, o.z, __uint_as_float(id));
-        st.B[id] = make_float4(dir.x, dir.y, dir.z, 1.0f);
+        Ray r = camera_ray(sc.cam, ps, pixel, ps.sample_base + s);
+        st.A[id] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(id));
+        st.B[id] = make_float4(r.d.x, r.d.y, r.d.z, 1.0f);
         st.C[id] = make_float2(1.0f, 1.0f);
     }
 }
@@ -439,9 +446,75 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
 }
 
-// main.cu:59-64 for every path of the queue: emitted(), scatter(), throughput, termination.
-// A path's radiance is known only when it ends -- emitted() is non-zero only for diffuse_light,
-// whose scatter() returns false (material.h:295-304) -- so it is written once, to rad[path id].
+// main.cu:59-64 for one hit: emitted(), scatter(), throughput.  Returns true when the path goes on
+// (out_r, out_T are its next ray and throughput); otherwise `result` is the path's final radiance:
+// emitted() is non-zero only for diffuse_light, whose scatter() returns false (material.h:295-304),
+// so a path's radiance is known exactly when it ends and is T * (emit | background | black).
+PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const Ray &r, v3 T, uint32_t pixel, uint32_t sample_abs,
+                     int32_t bounce, const PrimRec &q, float t, Ray &out_r, v3 &out_T, v3 &result)
+{
+    v3 p, normal;
+    bool front;
+    surface_at(q, r, t, p, normal, front);
+    const uint32_t mtype = (q.meta >> 3) & 3u;
+    const float4 m = mats[q.meta >> 5];
+    Rng g;
+    g.pixel = pixel; g.sample = sample_abs; g.bounce = (uint32_t)bounce + 1u; g.block = 0;
+    g.k0 = ps.k0; g.k1 = ps.k1;
+    v3 dir = V(0.0f, 0.0f, 0.0f), atten = V(0.0f, 0.0f, 0.0f);
+    bool scattered = false;
+    result = V(0.0f, 0.0f, 0.0f);
+    if (mtype == PT_DIFFUSE_LIGHT) { // material.h:295-304
+        result = vmul(T, V(m.x, m.y, m.z));
+    } else if (mtype == PT_DIELECTRIC) { // material.h:223-242
+        float ir = m.x;
+        atten = V(1.0f, 1.0f, 1.0f);
+        float refraction_ratio = front ? (1.0f / ir) : ir;
+        v3 unit_direction = vunit(r.d);
+        float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool reflect_it = refraction_ratio * sin_theta > 1.0f;
+        if (!reflect_it) { // the uniform is consumed only when refraction is possible (material.h:235)
+            float u4[4];
+            rng_block(g, u4);
+            reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u4[0];
+        }
+        dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
+        scattered = true;
+    } else {
+        v3 rs = random_in_unit_sphere(g);
+        atten = V(m.x, m.y, m.z);
+        if (mtype == PT_LAMBERTIAN) { // material.h:90-99
+            dir = vadd(normal, vunit(rs));
+            if (vnear_zero(dir)) dir = normal;
+            scattered = true;
+        } else { // metal, material.h:155-162
+            v3 reflected = vreflect(vunit(r.d), normal);
+            dir = vadd(reflected, vscale(m.w, rs));
+            scattered = vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
+        }
+    }
+    // main.cu:64: attenuation * ray_color(scattered, depth - 1); at the last allowed bounce the next
+    // ray_color call has depth <= 0 and returns black (main.cu:50-51)
+    const bool go_on = scattered && (bounce + 1 < ps.max_depth);
+    out_r.o = p;
+    out_r.d = dir;
+    out_T = vmul(T, atten);
+    return go_on;
+}
+
+PT_DI PrimRec load_prim(const PrimRec *arr, uint32_t slot)
+{
+    const float4 *pp = reinterpret_cast<const float4 *>(arr + slot);
+    float4 w0 = pp[0], w1 = pp[1];
+    PrimRec q;
+    q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+    q.meta = __float_as_uint(w1.z);
+    q.id = __float_as_uint(w1.w);
+    return q;
+}
+
+// Shades every path of the queue and compacts the survivors into the next queue.
 __global__ __launch_bounds__(PT_BLOCK) void k_shade(SceneDev sc, PassDev ps, PathPlanes in, const uint2 *__restrict__ hits,
                                                     PathPlanes out, const uint32_t *__restrict__ n_in_ptr,
                                                     uint32_t *n_out_ptr, float *__restrict__ rad, int32_t bounce)
@@ -450,7 +523,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(SceneDev sc, PassDev ps, Pat
     __shared__ uint32_t s_base;
     const uint32_t n = *n_in_ptr;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool last = (bounce + 1 >= ps.max_depth);
     for (uint32_t base = blockIdx.x * PT_BLOCK; base < n; base += gridDim.x * PT_BLOCK) {
         uint32_t i = base + threadIdx.x;
         bool survive = false;
@@ -465,67 +537,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(SceneDev sc, PassDev ps, Pat
             Ray r;
             r.o = V(A.x, A.y, A.z);
             r.d = V(B.x, B.y, B.z);
-            v3 result = V(0.0f, 0.0f, 0.0f);
+            v3 result;
             if (hh.y == PT_NO_PRIM) {
                 result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
             } else {
-                const PrimRec *arr = (hh.y & 0x80000000u) ? sc.prims_list : sc.prims;
-                const float4 *pp = reinterpret_cast<const float4 *>(arr + (hh.y & 0x7FFFFFFFu));
-                float4 w0 = pp[0], w1 = pp[1];
-                PrimRec q;
-                q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
-                q.meta = __float_as_uint(w1.z);
-                q.id = __float_as_uint(w1.w);
-                float t = __uint_as_float(hh.x);
-                v3 p, normal;
-                bool front;
-                surface_at(q, r, t, p, normal, front);
-                const uint32_t mtype = (q.meta >> 3) & 3u;
-                const float4 m = sc.mats[q.meta >> 5];
+                PrimRec q = load_prim((hh.y & 0x80000000u) ? sc.prims_list : sc.prims, hh.y & 0x7FFFFFFFu);
                 uint32_t s = id / ps.n_pixels, pixel = id - s * ps.n_pixels;
-                Rng g;
-                g.pixel = pixel; g.sample = ps.sample_base + s; g.bounce = (uint32_t)bounce + 1u; g.block = 0;
-                g.k0 = ps.k0; g.k1 = ps.k1;
-                v3 dir = V(0.0f, 0.0f, 0.0f), atten = V(0.0f, 0.0f, 0.0f);
-                bool scattered = false;
-                if (mtype == PT_DIFFUSE_LIGHT) { // material.h:295-304
-                    result = vmul(T, V(m.x, m.y, m.z));
-                } else if (mtype == PT_DIELECTRIC) { // material.h:223-242
-                    float ir = m.x;
-                    atten = V(1.0f, 1.0f, 1.0f);
-                    float refraction_ratio = front ? (1.0f / ir) : ir;
-                    v3 unit_direction = vunit(r.d);
-                    float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
-                    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-                    bool reflect_it = refraction_ratio * sin_theta > 1.0f;
-                    if (!reflect_it) { // the uniform is consumed only when refraction is possible (material.h:235)
-                        float u4[4];
-                        rng_block(g, u4);
-                        reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u4[0];
-                    }
-                    dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
-                    scattered = true;
-                } else {
-                    v3 rs = random_in_unit_sphere(g);
-                    atten = V(m.x, m.y, m.z);
-                    if (mtype == PT_LAMBERTIAN) { // material.h:90-99
-                        dir = vadd(normal, vunit(rs));
-                        if (vnear_zero(dir)) dir = normal;
-                        scattered = true;
-                    } else { // metal, material.h:155-162
-                        v3 reflected = vreflect(vunit(r.d), normal);
-                        dir = vadd(reflected, vscale(m.w, rs));
-                        scattered = vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
-                    }
+                Ray nr;
+                v3 nT;
+                survive = shade_hit(sc.mats, ps, r, T, pixel, ps.sample_base + s, bounce, q, __uint_as_float(hh.x), nr, nT, result);
+                if (survive) {
+                    oA = make_float4(nr.o.x, nr.o.y, nr.o.z, A.w);
+                    oB = make_float4(nr.d.x, nr.d.y, nr.d.z, nT.x);
+                    oC = make_float2(nT.y, nT.z);
                 }
-                if (scattered && !last) { // main.cu:64: attenuation * ray_color(scattered, depth - 1)
-                    survive = true;
-                    v3 Tn = vmul(T, atten);
-                    oA = make_float4(p.x, p.y, p.z, A.w);
-                    oB = make_float4(dir.x, dir.y, dir.z, Tn.x);
-                    oC = make_float2(Tn.y, Tn.z);
-                }
-                // scattered && last: the next ray_color call has depth <= 0 and returns black (main.cu:50-51)
             }
             if (!survive) {
                 rad[3 * (size_t)id + 0] = result.x;
@@ -551,6 +576,169 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(SceneDev sc, PassDev ps, Pat
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent-workgroup wavefront: the same stages (camera ray -> nearest hit -> scatter/emit ->
+// compaction -> film), but a workgroup owns a SLICE of paths (all samples of a run of pixels) and
+// takes it through every bounce itself.  Its two ping-pong queues and its radiance buffer are a
+// private region of HBM (cache-resident in practice), queue lengths live in LDS, compaction is a
+// wave ballot + one LDS atomic per wave, stages are separated by workgroup barriers instead of
+// kernel launches, and slices are handed out by a ticket counter.  No global atomics on the path,
+// no per-bounce launches, no latency-bound tail launches.
+// ---------------------------------------------------------------------------------------------
+struct SliceDev {
+    float4 *qA;   // [grid][2][cap]
+    float4 *qB;
+    float2 *qC;
+    float *rad;   // [grid][cap*3]
+    uint32_t cap; // paths per slice = pix_per_slice * samples
+    uint32_t pix_per_slice, n_slices;
+    uint32_t *ticket;
+};
+
+template <bool COUNT, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
+{
+    extern __shared__ float4 s_mem[];
+    __shared__ uint32_t s_slice, s_out[2];
+    uint32_t *s_stack;
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims};
+    if (LDS) {
+        float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
+        s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
+        const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
+        for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) s_nodes[(i & 3u) * sc.n_nodes + (i >> 2)] = gn[i];
+        for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
+        lsrc.nodes = s_nodes;
+        lsrc.prims = s_prims;
+    } else {
+        s_stack = reinterpret_cast<uint32_t *>(s_mem);
+    }
+    GlobalSrc gsrc{sc.nodes, sc.prims};
+    const uint32_t cap = sl.cap;
+    float4 *const qA = sl.qA + (size_t)blockIdx.x * 2 * cap;
+    float4 *const qB = sl.qB + (size_t)blockIdx.x * 2 * cap;
+    float2 *const qC = sl.qC + (size_t)blockIdx.x * 2 * cap;
+    float *const rad = sl.rad + (size_t)blockIdx.x * 3 * cap;
+    const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
+    unsigned long long rays = 0;
+    uint32_t nb = 0, np = 0, nf = 0;
+
+    for (;;) {
+        __syncthreads(); // previous slice's film pass is done with rad and the queues
+        if (threadIdx.x == 0) s_slice = atomicAdd(sl.ticket, 1u);
+        __syncthreads();
+        const uint32_t slice = s_slice;
+        if (slice >= sl.n_slices) break;
+        const uint32_t pix0 = slice * sl.pix_per_slice;
+        const uint32_t npix = min(sl.pix_per_slice, ps.n_pixels - pix0);
+        uint32_t in_count = npix * ps.samples;
+        uint32_t cur = 0;
+        for (int32_t b = 0; b < ps.max_depth && in_count > 0; ++b) {
+            if (threadIdx.x == 0) s_out[b & 1] = 0;
+            __syncthreads();
+            const float4 *inA = qA + cur * cap, *inB = qB + cur * cap;
+            const float2 *inC = qC + cur * cap;
+            float4 *outA = qA + (cur ^ 1u) * cap, *outB = qB + (cur ^ 1u) * cap;
+            float2 *outC = qC + (cur ^ 1u) * cap;
+            for (uint32_t base = 0; base < in_count; base += BLOCK) {
+                const uint32_t i = base + threadIdx.x;
+                bool survive = false;
+                float4 oA, oB;
+                float2 oC;
+                if (i < in_count) {
+                    Ray r;
+                    v3 T;
+                    uint32_t lid; // path id inside the slice: s * npix + p
+                    if (b == 0) {
+                        lid = i;
+                        uint32_t s = i / npix, pl = i - s * npix;
+                        r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
+                        T = V(1.0f, 1.0f, 1.0f);
+                    } else {
+                        float4 A = inA[i], B = inB[i];
+                        float2 C = inC[i];
+                        lid = __float_as_uint(A.w);
+                        r.o = V(A.x, A.y, A.z);
+                        r.d = V(B.x, B.y, B.z);
+                        T = V(B.w, C.x, C.y);
+                    }
+                    bool need_exact;
+                    HitResult h;
+                    if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+                    else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+                    const PrimRec *arr = sc.prims;
+                    if (need_exact) { // resolved by the list-order scan; its slot indexes the list-order records
+                        h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+                        arr = sc.prims_list;
+                        nf++;
+                    }
+                    v3 result;
+                    if (h.slot == PT_NO_PRIM) {
+                        result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
+                    } else {
+                        PrimRec q = load_prim(arr, h.slot);
+                        uint32_t s = lid / npix, pl = lid - s * npix;
+                        Ray nr;
+                        v3 nT;
+                        survive = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, b, q, h.t, nr, nT, result);
+                        if (survive) {
+                            oA = make_float4(nr.o.x, nr.o.y, nr.o.z, __uint_as_float(lid));
+                            oB = make_float4(nr.d.x, nr.d.y, nr.d.z, nT.x);
+                            oC = make_float2(nT.y, nT.z);
+                        }
+                    }
+                    if (!survive) {
+                        rad[3 * lid + 0] = result.x;
+                        rad[3 * lid + 1] = result.y;
+                        rad[3 * lid + 2] = result.z;
+                    }
+                }
+                // compaction into the slice's next queue: ballot, one LDS atomic per wave
+                const unsigned long long mask = __ballot(survive);
+                if (mask) {
+                    const uint32_t pre = lane_prefix(mask);
+                    uint32_t pos0 = 0;
+                    if (survive && pre == 0) pos0 = atomicAdd(&s_out[b & 1], (uint32_t)__popcll(mask));
+                    pos0 = __shfl(pos0, __ffsll((long long)mask) - 1, 64);
+                    if (survive) {
+                        outA[pos0 + pre] = oA;
+                        outB[pos0 + pre] = oB;
+                        outC[pos0 + pre] = oC;
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) rays += in_count;
+            in_count = s_out[b & 1];
+            cur ^= 1u;
+        }
+        // film: col += ray_color(...) in sample order (main.cu:93) for the slice's pixels
+        __syncthreads();
+        for (uint32_t pl = threadIdx.x; pl < npix; pl += BLOCK) {
+            const size_t px = (size_t)(pix0 + pl) * 3;
+            float r = rgb_sum[px], g = rgb_sum[px + 1], bl = rgb_sum[px + 2];
+            for (uint32_t s = 0; s < ps.samples; ++s) {
+                const uint32_t lid = s * npix + pl;
+                r += rad[3 * lid];
+                g += rad[3 * lid + 1];
+                bl += rad[3 * lid + 2];
+            }
+            rgb_sum[px] = r;
+            rgb_sum[px + 1] = g;
+            rgb_sum[px + 2] = bl;
+        }
+    }
+    if (threadIdx.x == 0 && rays) atomicAdd(&cnt->rays, rays);
+    if (COUNT) {
+        unsigned long long sb = wave_sum_u32(nb), sp = wave_sum_u32(np);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&cnt->box_tests, sb);
+            atomicAdd(&cnt->prim_tests, sp);
+        }
+    }
+    if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
 }
 
 // col += ray_color(...) in sample order (main.cu:93), and the pass's ray count.
@@ -602,6 +790,12 @@ struct pt_context {
     uint32_t *d_nactive = nullptr;
     size_t cap_nactive = 0;
     Counters *d_cnt = nullptr;
+    // persistent-workgroup path kernel workspace
+    size_t cap_slice_paths = 0; // grid * cap
+    float4 *d_sA = nullptr, *d_sB = nullptr;
+    float2 *d_sC = nullptr;
+    float *d_srad = nullptr;
+    uint32_t *d_ticket = nullptr;
     // pt_trace_rays staging
     float *d_ro = nullptr, *d_rd = nullptr;
     pt_hit *d_rh = nullptr;
@@ -663,6 +857,7 @@ extern "C" void pt_context_destroy(pt_context *ctx)
     free_scene(ctx);
     free_workspace(ctx);
     hipFree(ctx->d_nactive); hipFree(ctx->d_cnt);
+    hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad); hipFree(ctx->d_ticket);
     hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
     for (hipEvent_t e : ctx->events) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -759,7 +954,8 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     std::string e = validate_desc(desc);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     pt::BvhBuild b;
-    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    const uint32_t leaf_max = getenv("PT_LEAF_MAX") ? (uint32_t)atoi(getenv("PT_LEAF_MAX")) : PT_LEAF_MAX; // tuning knob
+    e = pt::build_bvh(*desc, leaf_max, b);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     if (b.max_depth > 96) return fail(ctx, PT_ERR_LIMIT, "BVH deeper than 96 levels");
     std::vector<PrimRec> leaf, list;
@@ -922,6 +1118,123 @@ struct StageTimer {
     void end() { if (on) hipEventRecord(get(), stream); }
 };
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <bool COUNT>
+static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, uint32_t grid, size_t lds_bytes, const PassDev &ps,
+                         const SliceDev &sl, float *d_rgb_sum)
+{
+#define PT_LAUNCH_PATHS(L, B) hipLaunchKernelGGL((k_paths<COUNT, L, B>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+    if (lds) {
+        if (block == 256) PT_LAUNCH_PATHS(true, 256);
+        else if (block == 512) PT_LAUNCH_PATHS(true, 512);
+        else PT_LAUNCH_PATHS(true, 1024);
+    } else {
+        if (block == 256) PT_LAUNCH_PATHS(false, 256);
+        else if (block == 512) PT_LAUNCH_PATHS(false, 512);
+        else PT_LAUNCH_PATHS(false, 1024);
+    }
+#undef PT_LAUNCH_PATHS
+}
+
+// The persistent-workgroup pipeline (k_paths).  Tuning knobs are read from the environment once:
+// PT_PATHS_BLOCK (256|512|1024), PT_PATHS_LDS (0|1), PT_PATHS_PER_CU, PT_PATHS_SLICE (paths per slice).
+static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
+{
+    const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
+    const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
+    const bool want_lds = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0 && env_int("PT_PATHS_LDS", 1) != 0;
+    int block = env_int("PT_PATHS_BLOCK", 512);
+    if (block != 256 && block != 512 && block != 1024) block = 512;
+    const SceneDev &sc = ctx->sc;
+    const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
+    const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32;
+    bool lds = want_lds && scene_bytes + stack_bytes <= 64 * 1024;
+    const size_t lds_bytes = stack_bytes + (lds ? scene_bytes : 0);
+    int per_cu = env_int("PT_PATHS_PER_CU", 0);
+    if (per_cu <= 0) {
+        per_cu = std::min<int>(2048 / block, (int)((160 * 1024) / std::max<size_t>(lds_bytes + 64, 1)));
+        per_cu = std::max(per_cu, 1);
+    }
+    const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
+
+    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", 16384));
+    uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
+    spass = std::min(spass, pr->spp);
+    uint32_t pix = std::max(64u, (target / spass) & ~63u);
+    const uint32_t cap = pix * spass;
+    if ((uint64_t)cap * 3 >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one slice");
+    const uint32_t n_slices = (n_pixels + pix - 1) / pix;
+    const uint32_t grid = std::min(grid_max, n_slices);
+
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = (size_t)grid * cap;
+    if (need > ctx->cap_slice_paths) {
+        hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad);
+        ctx->d_sA = ctx->d_sB = nullptr; ctx->d_sC = nullptr; ctx->d_srad = nullptr; ctx->cap_slice_paths = 0;
+        PT_HIP(ctx, hipMalloc(&ctx->d_sA, need * 2 * sizeof(float4)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_sB, need * 2 * sizeof(float4)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_sC, need * 2 * sizeof(float2)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_srad, need * 3 * sizeof(float)));
+        ctx->cap_slice_paths = need;
+    }
+    if (!ctx->d_ticket) PT_HIP(ctx, hipMalloc(&ctx->d_ticket, sizeof(uint32_t)));
+
+    StageTimer tm(ctx, stream, (pr->flags & PT_RENDER_STAGE_TIMES) != 0);
+    hipEvent_t ev0 = tm.get(), ev1 = tm.get();
+    PT_HIP(ctx, hipEventRecord(ev0, stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
+    PassDev ps;
+    ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
+    ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
+    ps.max_depth = pr->max_depth;
+    SliceDev sl;
+    sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
+    sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.ticket = ctx->d_ticket;
+    uint32_t n_passes = 0;
+    for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
+        ps.samples = std::min(spass, pr->spp - done);
+        ps.sample_base = pr->sample_offset + done;
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
+        tm.begin(1);
+        if (count) launch_paths<true>(ctx, stream, block, lds, grid, lds_bytes, ps, sl, d_rgb_sum);
+        else launch_paths<false>(ctx, stream, block, lds, grid, lds_bytes, ps, sl, d_rgb_sum);
+        tm.end();
+    }
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipEventRecord(ev1, stream));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        Counters h;
+        PT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_cnt, sizeof h, hipMemcpyDeviceToHost, stream));
+        PT_HIP(ctx, hipStreamSynchronize(stream));
+        stats->rays = h.rays;
+        stats->primary_rays = (uint64_t)pr->spp * n_pixels;
+        stats->box_tests = h.box_tests;
+        stats->prim_tests = h.prim_tests;
+        stats->exact_fallbacks = h.exact_fallbacks;
+        stats->launches_intersect = n_passes;
+        stats->passes = n_passes;
+        float ms = 0.0f;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+        stats->ms_total = ms;
+        if (tm.on) {
+            double acc = 0;
+            for (size_t k = 0; k < tm.stage.size(); ++k) {
+                float m = 0.0f;
+                PT_HIP(ctx, hipEventElapsedTime(&m, ctx->events[2 + 2 * k], ctx->events[3 + 2 * k]));
+                acc += m;
+            }
+            stats->ms_paths = acc;
+        }
+    }
+    return PT_OK;
+}
+
 extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, void *stream_,
                                       pt_stats *stats)
 {
@@ -937,6 +1250,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((pr->flags & PT_RENDER_SPLIT_KERNELS) == 0) return render_slices(ctx, pr, d_rgb_sum, stream, stats);
 
     // samples of every pixel in flight per pass: as many as fit the path budget
     const uint64_t budget = 1ull << 27; // 134M paths in flight = 13.4 GB of queues: tail bounces are paid once per pass
