@@ -70,10 +70,7 @@ class PtStats(C.Structure):
 HIT_DTYPE = np.dtype(
     [("t", "<f4"), ("prim", "<u4"), ("n", "<f4", (3,)), ("front", "<u4"), ("p", "<f4", (3,)), ("flags", "<u4")]
 )
-NODE_DTYPE = np.dtype(
-    [("lo0", "<f4", (3,)), ("c0", "<i4"), ("hi0", "<f4", (3,)), ("c1", "<i4"), ("lo1", "<f4", (3,)), ("pad0", "<u4"),
-     ("hi1", "<f4", (3,)), ("pad1", "<u4")]
-)
+NODE_DTYPE = np.dtype([("lo", "<f4", (3, 2)), ("hi", "<f4", (3, 2)), ("c", "<i4", (2,)), ("pad", "<u4", (2,))])  # [axis][child]
 
 _lib = None
 

@@ -146,12 +146,12 @@ struct Builder {
         int32_t c1 = nr > leaf_max ? build_inner(first + nl, nr, depth + 1) : leaf_ref(first + nl, nr);
         HostNode &n = nodes[me];
         for (int a = 0; a < 3; ++a) {
-            n.lo0[a] = bl.lo[a]; n.hi0[a] = bl.hi[a];
-            n.lo1[a] = br.lo[a]; n.hi1[a] = br.hi[a];
+            n.lo[a][0] = bl.lo[a]; n.hi[a][0] = bl.hi[a];
+            n.lo[a][1] = br.lo[a]; n.hi[a][1] = br.hi[a];
         }
-        n.c0 = c0;
-        n.c1 = c1;
-        n.pad0 = n.pad1 = 0;
+        n.c[0] = c0;
+        n.c[1] = c1;
+        n.pad[0] = n.pad[1] = 0;
         return me;
     }
 };
@@ -220,11 +220,11 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
         HostNode n{};
         Box bl = b.range_box(0, d.n_prims);
         for (int a = 0; a < 3; ++a) {
-            n.lo0[a] = bl.lo[a]; n.hi0[a] = bl.hi[a];
-            n.lo1[a] = kInf; n.hi1[a] = -kInf;
+            n.lo[a][0] = bl.lo[a]; n.hi[a][0] = bl.hi[a];
+            n.lo[a][1] = kInf; n.hi[a][1] = -kInf;
         }
-        n.c0 = Builder::leaf_ref(0, d.n_prims);
-        n.c1 = Builder::leaf_ref(0, 1);
+        n.c[0] = Builder::leaf_ref(0, d.n_prims);
+        n.c[1] = Builder::leaf_ref(0, 1);
         out.nodes.push_back(n);
         b.max_depth = 1;
     }

@@ -8,11 +8,11 @@
 
 namespace pt {
 
-struct HostNode { // mirrors BvhNode (pt_device.h), 64 B
-    float lo0[3]; int32_t c0;
-    float hi0[3]; int32_t c1;
-    float lo1[3]; uint32_t pad0;
-    float hi1[3]; uint32_t pad1;
+struct HostNode { // mirrors BvhNode (pt_device.h), 64 B: child boxes interleaved per axis
+    float lo[3][2];
+    float hi[3][2];
+    int32_t c[2];
+    uint32_t pad[2];
 };
 static_assert(sizeof(HostNode) == 64, "HostNode must be 64 bytes");
 

@@ -29,14 +29,15 @@ struct __attribute__((aligned(16))) PrimRec {
 };
 static_assert(sizeof(PrimRec) == 32, "PrimRec must be 32 bytes");
 
-// One inner node, 64 B: the boxes of both children and their references.
+// One inner node, 64 B: the boxes of both children, interleaved per axis so that one packed
+// instruction handles both (lo[a][k] = lower bound of child k on axis a), and their references.
 //   ref >= 0: inner node index.  ref < 0: leaf, ~ref = (first_prim << 3) | (count - 1).
 //   An absent child has an inverted box (lo = +inf, hi = -inf) and ref = leaf of count 1 at 0.
 struct __attribute__((aligned(16))) BvhNode {
-    float lo0[3]; int32_t c0;
-    float hi0[3]; int32_t c1;
-    float lo1[3]; uint32_t pad0;
-    float hi1[3]; uint32_t pad1;
+    float lo[3][2];
+    float hi[3][2];
+    int32_t c[2];
+    uint32_t pad[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 

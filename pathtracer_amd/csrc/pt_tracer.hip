@@ -92,22 +92,51 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
     return best;
 }
 
+// Per-ray constants of the slab test in FMA form: t = bound * inv - origin * inv.
 struct BoxRay {
-    float ox, oy, oz, ix, iy, iz;
+    float ix, iy, iz;    // 1/d
+    float nox, noy, noz; // -(o * (1/d))
+    float eps;           // absolute error bound of t from rounding origin * inv
 };
 
-// Conservative slab test (the role of aabb::hit, aabb.h:78-91).  It only prunes, so its arithmetic
-// is free-form; NaNs from 0*inf drop out of fminf/fmaxf, and the interval is widened by 2^-21
-// relative on both ends so that rounding here can never reject a box the exact test accepts.
-PT_DI bool box_test(const float *lo, const float *hi, const BoxRay &b, float t_min, float t_best, float &t_near)
+PT_DI BoxRay make_box_ray(const Ray &r)
 {
-    float t0x = (lo[0] - b.ox) * b.ix, t1x = (hi[0] - b.ox) * b.ix;
-    float t0y = (lo[1] - b.oy) * b.iy, t1y = (hi[1] - b.oy) * b.iy;
-    float t0z = (lo[2] - b.oz) * b.iz, t1z = (hi[2] - b.oz) * b.iz;
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), t_min));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), t_best));
-    t_near = tn;
-    return tn * 0.99999952f <= tf * 1.00000048f;
+    // A component of exactly (or nearly) zero would make inv infinite and bound*inv - origin*inv a
+    // one-sided NaN; the box test sees such a ray as very slightly tilted instead (2^-60), which keeps
+    // every distance finite.  Only the pruning test sees this value; hit arithmetic uses the true ray.
+    const float tiny = 8.6736174e-19f;
+    const float dx = fabsf(r.d.x) < tiny ? copysignf(tiny, r.d.x) : r.d.x;
+    const float dy = fabsf(r.d.y) < tiny ? copysignf(tiny, r.d.y) : r.d.y;
+    const float dz = fabsf(r.d.z) < tiny ? copysignf(tiny, r.d.z) : r.d.z;
+    BoxRay b;
+    b.ix = 1.0f / dx; b.iy = 1.0f / dy; b.iz = 1.0f / dz;
+    const float ox = r.o.x * b.ix, oy = r.o.y * b.iy, oz = r.o.z * b.iz;
+    b.nox = -ox; b.noy = -oy; b.noz = -oz;
+    b.eps = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * (1.0f / 4194304.0f); // 2^-22 * max|o*inv|: twice the rounding bound
+    return b;
+}
+
+// Conservative slab test of both child boxes (the role of aabb::hit, aabb.h:78-91).  It only prunes, so
+// its arithmetic is free-form: one FMA per plane distance.  Rounding can move a distance by at most
+// |o*inv| * 2^-24 absolutely and 2^-23 relatively, so the far end is widened by eps + 2^-21 relative
+// before the comparison.  A box the exact test accepts is therefore never rejected; a ray with a
+// near-zero direction component has a huge eps and simply prunes less.
+PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const BoxRay &b, float t_min, float t_best,
+                     bool &h0, bool &h1, float &tn0, float &tn1)
+{
+    // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z)
+    const float a0x = __builtin_fmaf(q0.x, b.ix, b.nox), a1x = __builtin_fmaf(q0.y, b.ix, b.nox);
+    const float a0y = __builtin_fmaf(q0.z, b.iy, b.noy), a1y = __builtin_fmaf(q0.w, b.iy, b.noy);
+    const float a0z = __builtin_fmaf(q1.x, b.iz, b.noz), a1z = __builtin_fmaf(q1.y, b.iz, b.noz);
+    const float b0x = __builtin_fmaf(q1.z, b.ix, b.nox), b1x = __builtin_fmaf(q1.w, b.ix, b.nox);
+    const float b0y = __builtin_fmaf(q2.x, b.iy, b.noy), b1y = __builtin_fmaf(q2.y, b.iy, b.noy);
+    const float b0z = __builtin_fmaf(q2.z, b.iz, b.noz), b1z = __builtin_fmaf(q2.w, b.iz, b.noz);
+    tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), t_min));
+    tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), t_min));
+    const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), t_best));
+    const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), t_best));
+    h0 = tn0 <= __builtin_fmaf(tf0, 1.00000048f, b.eps);
+    h1 = tn1 <= __builtin_fmaf(tf1, 1.00000048f, b.eps);
 }
 
 // Nearest hit through the BVH, with the list scan's semantics:
@@ -156,9 +185,7 @@ template <bool COUNT, int STRIDE, class Src>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim)
 {
-    BoxRay br;
-    br.ox = r.o.x; br.oy = r.o.y; br.oz = r.o.z;
-    br.ix = 1.0f / r.d.x; br.iy = 1.0f / r.d.y; br.iz = 1.0f / r.d.z;
+    const BoxRay br = make_box_ray(r);
 
     float best_t = t_max;
     uint32_t best_slot = PT_NO_PRIM, best_id = 0;
@@ -174,12 +201,10 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         if (cur >= 0) {
             float4 a, b, c, d;
             src.node(cur, a, b, c, d);
-            float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {b.x, b.y, b.z};
-            float lo1[3] = {c.x, c.y, c.z}, hi1[3] = {d.x, d.y, d.z};
-            int32_t c0 = __float_as_int(a.w), c1 = __float_as_int(b.w);
+            const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
             float tn0, tn1;
-            bool h0 = box_test(lo0, hi0, br, t_min, best_t, tn0);
-            bool h1 = box_test(lo1, hi1, br, t_min, best_t, tn1);
+            bool h0, h1;
+            box_test2(a, b, c, br, t_min, best_t, h0, h1, tn0, tn1);
             if (COUNT) n_box += 2;
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
@@ -598,7 +623,7 @@ struct SliceDev {
 };
 
 template <bool COUNT, bool LDS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
+__global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
     extern __shared__ float4 s_mem[];
     __shared__ uint32_t s_slice, s_out[2];
@@ -1162,7 +1187,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
 
-    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", 16384));
+    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", 32768));
     uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
     spass = std::min(spass, pr->spp);
     uint32_t pix = std::max(64u, (target / spass) & ~63u);

@@ -18,13 +18,13 @@ out = {}
 for k in sorted(agg):
     out[k] = {c: {"sum": v, "launches": len(launches[k][c]), "per_launch": v / max(1, len(launches[k][c]))} for c, v in sorted(agg[k].items())}
 summary = {"workload": workload, "kernels": out}
-ki = next((k for k in out if k.startswith("k_intersect<false>")), None)
+ki = next((k for k in out if k.startswith("k_paths<false")), None) or next((k for k in out if k.startswith("k_intersect<false")), None)
 res = {}
 if ki and "FETCH_SIZE" in out[ki] and "WRITE_SIZE" in out[ki]:
     fetch = out[ki]["FETCH_SIZE"]["per_launch"] * 1024.0
     write = out[ki]["WRITE_SIZE"]["per_launch"] * 1024.0
-    res = {"k_intersect_fetch_bytes_per_launch_raw": fetch, "k_intersect_write_bytes_per_launch": write,
-           "k_intersect_hbm_bytes_per_launch": 2.0 * fetch + write,
+    res = {"kernel": ki, "fetch_bytes_per_launch_raw": fetch, "write_bytes_per_launch": write,
+           "hbm_bytes_per_launch": 2.0 * fetch + write,
            "note": "memory-side bytes per launch: 2 x FETCH_SIZE (gfx950 counts 128-B read requests as 64 B) + WRITE_SIZE; Infinity-Cache hits are included"}
 summary["derived"] = res
 json.dump(summary, open(os.path.join(root, "summary.json"), "w"), indent=1)

@@ -82,11 +82,12 @@ def _check_tree(desc, nodes, order, leaf_max=4):
                 assert (plo >= lo - 1e-6).all() and (phi <= hi + 1e-6).all()  # the (padded) node box encloses the object
             return depth
         nd = nodes[ref]
-        for clo, chi in ((nd["lo0"], nd["hi0"]), (nd["lo1"], nd["hi1"])):
+        kids = [(nd["lo"][:, k], nd["hi"][:, k]) for k in range(2)]
+        for clo, chi in kids:
             if np.isfinite(clo).all():
                 assert (clo >= lo - 1e-6).all() and (chi <= hi + 1e-6).all()  # children inside the parent
-        d0 = walk(int(nd["c0"]), nd["lo0"], nd["hi0"], depth + 1)
-        d1 = walk(int(nd["c1"]), nd["lo1"], nd["hi1"], depth + 1) if np.isfinite(nd["lo1"]).all() else depth
+        d0 = walk(int(nd["c"][0]), kids[0][0], kids[0][1], depth + 1)
+        d1 = walk(int(nd["c"][1]), kids[1][0], kids[1][1], depth + 1) if np.isfinite(kids[1][0]).all() else depth
         return max(d0, d1)
 
     inf = np.full(3, np.inf)
@@ -119,7 +120,7 @@ def test_bvh_degenerate_inputs():
     one.sphere((0, 0, 0), 1, one.lambertian((1, 1, 1)))
     one.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
     nodes, order, max_depth = api.bvh_build_host(one.desc())
-    assert len(nodes) == 1 and max_depth == 1 and list(order) == [0] and not np.isfinite(nodes[0]["lo1"]).any()
+    assert len(nodes) == 1 and max_depth == 1 and list(order) == [0] and not np.isfinite(nodes[0]["lo"][:, 1]).any()
 
 
 def test_bad_scenes_are_rejected_not_crashed():
