@@ -131,9 +131,8 @@ def main():
     rays_step = rays_t.item()
     elapsed = el_t.item()
 
-    # Dominant kernel (k_intersect): launch durations from HIP events recorded by the library on the
-    # launch stream, in a separate pass over the same workload (per-launch events perturb the pipeline,
-    # so they stay out of the timed region).
+    # Dominant kernel (k_paths, the persistent-workgroup wavefront kernel): launch durations from HIP events
+    # recorded by the library on the launch stream around every k_paths launch of one more step.
     prof = step(want_stats=True, flags=api.RENDER_STAGE_TIMES)
     torch.cuda.synchronize()
     cnt = None
@@ -145,25 +144,25 @@ def main():
     if rank == 0:
         bpr, fpr = bytes_per_ray(wl["B"], wl["P"]), flops_per_ray(wl["B"], wl["P"])
         n_launch = max(1, prof["launches_intersect"])
-        ms_launch = prof["ms_intersect"] / n_launch
+        ms_launch = prof["ms_paths"] / n_launch
         rays_launch = prof["rays"] / n_launch
         achieved = bpr * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("k_intersect_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_paths", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_ray": bpr, "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
-            "ms_intersect": prof["ms_intersect"], "ms_shade": prof["ms_shade"], "ms_raygen": prof["ms_raygen"], "ms_film": prof["ms_film"],
             "valu": {"achieved_tflops": fpr * rays_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0,
                      "peak_tflops": VALU_PEAK_TFLOPS, "peak_kind": "fp32 vector, non-packed", "flops_per_ray": fpr},
-            "note": "algorithmic bytes (32B+32P+100 per ray) over event-timed k_intersect launches of a separate pass; "
-                    "this scene's nodes and objects are cache-resident, so the figure is a rate of useful bytes, not HBM traffic",
+            "note": "algorithmic bytes (32B+32P+100 per ray) over event-timed k_paths launches; for cache-resident scenes the "
+                    "figure is a rate of useful bytes, not HBM traffic (see `traffic`, from rocprofv3 PMC passes); the kernel "
+                    "is VALU-issue-bound (profiles/)",
         }
         if cnt is not None and cnt["rays"]:
             roofline["measured_B"] = cnt["box_tests"] / cnt["rays"]

@@ -622,11 +622,15 @@ struct SliceDev {
     uint32_t *ticket;
 };
 
-template <bool COUNT, bool LDS, int BLOCK>
+template <bool COUNT, bool LDS, int BLOCK, bool SORT>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
+    constexpr int WAVES = BLOCK / 64;
     extern __shared__ float4 s_mem[];
     __shared__ uint32_t s_slice, s_out[2];
+    __shared__ uint2 s_hit[SORT ? BLOCK : 1];       // (t bits, slot) of the chunk's rays, by thread
+    __shared__ uint16_t s_perm[SORT ? BLOCK : 1];   // thread whose ray is shaded at each sorted position
+    __shared__ uint16_t s_bin[SORT ? 4 * WAVES : 1]; // per (class, wave) counts, then exclusive offsets
     uint32_t *s_stack;
     LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims};
     if (LDS) {
@@ -647,8 +651,23 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     float2 *const qC = sl.qC + (size_t)blockIdx.x * 2 * cap;
     float *const rad = sl.rad + (size_t)blockIdx.x * 3 * cap;
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long rays = 0;
     uint32_t nb = 0, np = 0, nf = 0;
+
+    // nearest hit of one ray; a list-order-resolved hit is returned with the top bit of the slot set
+    auto trace = [&](const Ray &r) -> HitResult {
+        bool need_exact;
+        HitResult h;
+        if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+        else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+        if (need_exact) {
+            h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+            if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
+            nf++;
+        }
+        return h;
+    };
 
     for (;;) {
         __syncthreads(); // previous slice's film pass is done with rad and the queues
@@ -667,43 +686,19 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
             const float2 *inC = qC + cur * cap;
             float4 *outA = qA + (cur ^ 1u) * cap, *outB = qB + (cur ^ 1u) * cap;
             float2 *outC = qC + (cur ^ 1u) * cap;
-            for (uint32_t base = 0; base < in_count; base += BLOCK) {
-                const uint32_t i = base + threadIdx.x;
+
+            // main.cu:54-64 for one traced ray, then compaction of the wave's survivors into the next queue
+            // (ballot + one LDS atomic per wave).  Every lane of the wave calls it; `valid` masks the idle ones.
+            auto shade_emit = [&](bool valid, const Ray &r, v3 T, uint32_t lid, HitResult h) {
                 bool survive = false;
                 float4 oA, oB;
                 float2 oC;
-                if (i < in_count) {
-                    Ray r;
-                    v3 T;
-                    uint32_t lid; // path id inside the slice: s * npix + p
-                    if (b == 0) {
-                        lid = i;
-                        uint32_t s = i / npix, pl = i - s * npix;
-                        r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
-                        T = V(1.0f, 1.0f, 1.0f);
-                    } else {
-                        float4 A = inA[i], B = inB[i];
-                        float2 C = inC[i];
-                        lid = __float_as_uint(A.w);
-                        r.o = V(A.x, A.y, A.z);
-                        r.d = V(B.x, B.y, B.z);
-                        T = V(B.w, C.x, C.y);
-                    }
-                    bool need_exact;
-                    HitResult h;
-                    if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
-                    else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
-                    const PrimRec *arr = sc.prims;
-                    if (need_exact) { // resolved by the list-order scan; its slot indexes the list-order records
-                        h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
-                        arr = sc.prims_list;
-                        nf++;
-                    }
+                if (valid) {
                     v3 result;
                     if (h.slot == PT_NO_PRIM) {
                         result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
                     } else {
-                        PrimRec q = load_prim(arr, h.slot);
+                        PrimRec q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
                         uint32_t s = lid / npix, pl = lid - s * npix;
                         Ray nr;
                         v3 nT;
@@ -720,7 +715,6 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         rad[3 * lid + 2] = result.z;
                     }
                 }
-                // compaction into the slice's next queue: ballot, one LDS atomic per wave
                 const unsigned long long mask = __ballot(survive);
                 if (mask) {
                     const uint32_t pre = lane_prefix(mask);
@@ -732,6 +726,96 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         outB[pos0 + pre] = oB;
                         outC[pos0 + pre] = oC;
                     }
+                }
+            };
+
+            for (uint32_t base = 0; base < in_count; base += BLOCK) {
+                const uint32_t i = base + threadIdx.x;
+                if (b == 0) {
+                    // camera rays are made on the fly; neighbouring pixels mostly hit the same material
+                    Ray r;
+                    HitResult h;
+                    h.t = 0.0f;
+                    h.slot = PT_NO_PRIM;
+                    if (i < in_count) {
+                        uint32_t s = i / npix, pl = i - s * npix;
+                        r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
+                        h = trace(r);
+                    }
+                    shade_emit(i < in_count, r, V(1.0f, 1.0f, 1.0f), i, h);
+                } else if (!SORT) {
+                    Ray r;
+                    v3 T = V(0.0f, 0.0f, 0.0f);
+                    uint32_t lid = 0;
+                    HitResult h;
+                    h.t = 0.0f;
+                    h.slot = PT_NO_PRIM;
+                    if (i < in_count) {
+                        float4 A = inA[i], B = inB[i];
+                        float2 C = inC[i];
+                        lid = __float_as_uint(A.w);
+                        r.o = V(A.x, A.y, A.z);
+                        r.d = V(B.x, B.y, B.z);
+                        T = V(B.w, C.x, C.y);
+                        h = trace(r);
+                    }
+                    shade_emit(i < in_count, r, T, lid, h);
+                } else {
+                    // Stage 1: nearest hit for the chunk's rays, in queue order.
+                    uint32_t cls = 3; // 0 ends without random numbers (miss, light) | 1 glass | 2 diffuse, metal | 3 no ray
+                    if (i < in_count) {
+                        float4 A = inA[i], B = inB[i];
+                        Ray r;
+                        r.o = V(A.x, A.y, A.z);
+                        r.d = V(B.x, B.y, B.z);
+                        HitResult h = trace(r);
+                        s_hit[threadIdx.x] = make_uint2(__float_as_uint(h.t), h.slot);
+                        cls = 0;
+                        if (h.slot != PT_NO_PRIM) {
+                            const PrimRec *arr = (h.slot & 0x80000000u) ? sc.prims_list : sc.prims;
+                            const uint32_t mtype = (arr[h.slot & 0x7FFFFFFFu].meta >> 3) & 3u;
+                            cls = mtype == PT_DIFFUSE_LIGHT ? 0u : (mtype == PT_DIELECTRIC ? 1u : 2u);
+                        }
+                    }
+                    // Stage 2: counting sort of the chunk by material class, so that the waves of stage 3 are
+                    // (nearly) homogeneous: the rejection-sampling loop runs in fewer, fuller waves.
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const unsigned long long m = __ballot(cls == k);
+                        if (cls == k) rank = lane_prefix(m);
+                        if (lane == 0) s_bin[k * WAVES + wave] = (uint16_t)__popcll(m);
+                    }
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        uint32_t acc = 0;
+                        for (int e = 0; e < 4 * WAVES; ++e) { uint32_t c = s_bin[e]; s_bin[e] = (uint16_t)acc; acc += c; }
+                    }
+                    __syncthreads();
+                    s_perm[s_bin[cls * WAVES + wave] + rank] = (uint16_t)threadIdx.x;
+                    __syncthreads();
+                    // Stage 3: shade in sorted order; the ray is re-read from the (cache-resident) queue.
+                    const uint32_t src = s_perm[threadIdx.x];
+                    const uint32_t i2 = base + src;
+                    Ray r;
+                    v3 T = V(0.0f, 0.0f, 0.0f);
+                    uint32_t lid = 0;
+                    HitResult h;
+                    h.t = 0.0f;
+                    h.slot = PT_NO_PRIM;
+                    if (i2 < in_count) {
+                        float4 A = inA[i2], B = inB[i2];
+                        float2 C = inC[i2];
+                        uint2 hh = s_hit[src];
+                        lid = __float_as_uint(A.w);
+                        r.o = V(A.x, A.y, A.z);
+                        r.d = V(B.x, B.y, B.z);
+                        T = V(B.w, C.x, C.y);
+                        h.t = __uint_as_float(hh.x);
+                        h.slot = hh.y;
+                    }
+                    shade_emit(i2 < in_count, r, T, lid, h);
+                    __syncthreads(); // s_hit / s_perm are reused by the next chunk
                 }
             }
             __syncthreads();
@@ -1150,31 +1234,32 @@ static int env_int(const char *name, int dflt)
 }
 
 template <bool COUNT>
-static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, uint32_t grid, size_t lds_bytes, const PassDev &ps,
-                         const SliceDev &sl, float *d_rgb_sum)
+static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
+                         const PassDev &ps, const SliceDev &sl, float *d_rgb_sum)
 {
-#define PT_LAUNCH_PATHS(L, B) hipLaunchKernelGGL((k_paths<COUNT, L, B>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_PATHS(L, B, S) hipLaunchKernelGGL((k_paths<COUNT, L, B, S>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_PATHS_S(L, B) do { if (sort) PT_LAUNCH_PATHS(L, B, true); else PT_LAUNCH_PATHS(L, B, false); } while (0)
     if (lds) {
-        if (block == 256) PT_LAUNCH_PATHS(true, 256);
-        else if (block == 512) PT_LAUNCH_PATHS(true, 512);
-        else PT_LAUNCH_PATHS(true, 1024);
+        if (block == 256) PT_LAUNCH_PATHS_S(true, 256);
+        else PT_LAUNCH_PATHS_S(true, 512);
     } else {
-        if (block == 256) PT_LAUNCH_PATHS(false, 256);
-        else if (block == 512) PT_LAUNCH_PATHS(false, 512);
-        else PT_LAUNCH_PATHS(false, 1024);
+        if (block == 256) PT_LAUNCH_PATHS_S(false, 256);
+        else PT_LAUNCH_PATHS_S(false, 512);
     }
+#undef PT_LAUNCH_PATHS_S
 #undef PT_LAUNCH_PATHS
 }
 
 // The persistent-workgroup pipeline (k_paths).  Tuning knobs are read from the environment once:
-// PT_PATHS_BLOCK (256|512|1024), PT_PATHS_LDS (0|1), PT_PATHS_PER_CU, PT_PATHS_SLICE (paths per slice).
+// PT_PATHS_BLOCK (256|512), PT_PATHS_LDS (0|1), PT_PATHS_PER_CU, PT_PATHS_SLICE (paths per slice), PT_PATHS_SORT (0|1).
 static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
 {
     const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
     const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
     const bool want_lds = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0 && env_int("PT_PATHS_LDS", 1) != 0;
     int block = env_int("PT_PATHS_BLOCK", 512);
-    if (block != 256 && block != 512 && block != 1024) block = 512;
+    if (block != 256 && block != 512) block = 512;
+    const bool sort = (pr->flags & PT_RENDER_NO_SORT) == 0 && env_int("PT_PATHS_SORT", 0) != 0; // measured slower on the spheres scene: opt-in
     const SceneDev &sc = ctx->sc;
     const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
     const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32;
@@ -1182,7 +1267,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const size_t lds_bytes = stack_bytes + (lds ? scene_bytes : 0);
     int per_cu = env_int("PT_PATHS_PER_CU", 0);
     if (per_cu <= 0) {
-        per_cu = std::min<int>(2048 / block, (int)((160 * 1024) / std::max<size_t>(lds_bytes + 64, 1)));
+        const size_t static_lds = 64 + (sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
+        per_cu = std::min<int>(2048 / block, (int)((160 * 1024) / std::max<size_t>(lds_bytes + static_lds, 1)));
         per_cu = std::max(per_cu, 1);
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
@@ -1226,8 +1312,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (count) launch_paths<true>(ctx, stream, block, lds, grid, lds_bytes, ps, sl, d_rgb_sum);
-        else launch_paths<false>(ctx, stream, block, lds, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        else launch_paths<false>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }
     PT_HIP(ctx, hipGetLastError());
