@@ -70,7 +70,7 @@ typedef struct pt_hit {
     float n[3];    /* face-forwarded normal */
     uint32_t front;
     float p[3];
-    uint32_t flags; /* bit 0: resolved by the exact list-order scan */
+    uint32_t flags; /* bit 1: list-order dependent, replayed over the ray's candidate objects; bit 0: resolved by the full list scan */
 } pt_hit;
 
 enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1 };
@@ -97,12 +97,13 @@ typedef struct pt_stats {
     uint64_t rays;         /* nearest-hit queries: one per (*world)->hit call at main.cu:54 */
     uint64_t primary_rays;
     uint64_t box_tests, prim_tests; /* only with PT_RENDER_COUNT_TESTS */
-    uint64_t exact_fallbacks;       /* rays resolved by the list-order scan */
+    uint64_t exact_fallbacks;       /* rays resolved by the full list-order scan (more than 16 candidate objects) */
     double ms_total;                /* device time of the whole call (events on the call's stream) */
     double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES | PT_RENDER_SPLIT_KERNELS */
     uint32_t launches_intersect; /* launches of the dominant kernel (k_intersect, or k_paths) */
     uint32_t passes;
     double ms_paths; /* only with PT_RENDER_STAGE_TIMES: summed k_paths launch time */
+    uint64_t exact_replays; /* rays whose list-order dependent answer was replayed over their candidate objects */
 } pt_stats;
 
 typedef struct pt_context pt_context;

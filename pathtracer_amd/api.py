@@ -60,7 +60,7 @@ class PtStats(C.Structure):
         ("rays", C.c_uint64), ("primary_rays", C.c_uint64), ("box_tests", C.c_uint64), ("prim_tests", C.c_uint64),
         ("exact_fallbacks", C.c_uint64), ("ms_total", C.c_double), ("ms_raygen", C.c_double),
         ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
-        ("launches_intersect", C.c_uint32), ("passes", C.c_uint32), ("ms_paths", C.c_double),
+        ("launches_intersect", C.c_uint32), ("passes", C.c_uint32), ("ms_paths", C.c_double), ("exact_replays", C.c_uint64),
     ]
 
     def as_dict(self):

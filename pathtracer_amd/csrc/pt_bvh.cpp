@@ -221,7 +221,7 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
         Box bl = b.range_box(0, d.n_prims);
         for (int a = 0; a < 3; ++a) {
             n.lo[a][0] = bl.lo[a]; n.hi[a][0] = bl.hi[a];
-            n.lo[a][1] = kInf; n.hi[a][1] = -kInf;
+            n.lo[a][1] = kInf; n.hi[a][1] = kInf; // a point at infinity: no ray reaches it
         }
         n.c[0] = Builder::leaf_ref(0, d.n_prims);
         n.c[1] = Builder::leaf_ref(0, 1);

@@ -32,7 +32,7 @@ static_assert(sizeof(PrimRec) == 32, "PrimRec must be 32 bytes");
 // One inner node, 64 B: the boxes of both children, interleaved per axis so that one packed
 // instruction handles both (lo[a][k] = lower bound of child k on axis a), and their references.
 //   ref >= 0: inner node index.  ref < 0: leaf, ~ref = (first_prim << 3) | (count - 1).
-//   An absent child has an inverted box (lo = +inf, hi = -inf) and ref = leaf of count 1 at 0.
+//   An absent child has the degenerate box lo = hi = +inf (no ray reaches it) and ref = leaf of count 1 at 0.
 struct __attribute__((aligned(16))) BvhNode {
     float lo[3][2];
     float hi[3][2];

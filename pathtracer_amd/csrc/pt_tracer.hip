@@ -50,7 +50,7 @@ struct PathPlanes {
 };
 
 struct Counters { // device memory, zeroed per call
-    unsigned long long rays, box_tests, prim_tests, exact_fallbacks;
+    unsigned long long rays, box_tests, prim_tests, exact_fallbacks, exact_replays;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -60,6 +60,22 @@ struct HitResult {
     float t;
     uint32_t slot; // index into the array that was searched; PT_NO_PRIM on a miss
 };
+
+// One object under the reference's control flow for a given t_max (the scan's running nearest t).
+PT_DI bool hit_any(const PrimRec &q, const Ray &r, float t_min, float t_max, float &t)
+{
+    switch (q.meta & 7u) {
+    case PT_SPHERE: return hit_sphere(q, r, t_min, t_max, t);
+    case PT_XY_RECT: return hit_rect<2, 0, 1>(q, r, t_min, t_max, t);
+    case PT_XZ_RECT: return hit_rect<1, 0, 2>(q, r, t_min, t_max, t);
+    case PT_YZ_RECT: return hit_rect<0, 1, 2>(q, r, t_min, t_max, t);
+    case PT_CONE: {
+        ConeRoots cr;
+        return cone_roots(q, r, cr) && hit_cone_ordered(cr, t_min, t_max, t);
+    }
+    default: return hit_cylinder(q, r, t_min, t_max, t);
+    }
+}
 
 // hittable_list::hit (hittable_list.h:87-101) over the list-order records: the definition of the
 // answer.  Used by PT_TRACE_LINEAR and to resolve the rare rays whose answer depends on list order.
@@ -71,20 +87,7 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
     for (uint32_t i = 0; i < n; ++i) {
         PrimRec q = list[i];
         float t;
-        bool h;
-        switch (q.meta & 7u) {
-        case PT_SPHERE: h = hit_sphere(q, r, t_min, best.t, t); break;
-        case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best.t, t); break;
-        case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best.t, t); break;
-        case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, best.t, t); break;
-        case PT_CONE: {
-            ConeRoots cr;
-            h = cone_roots(q, r, cr) && hit_cone_ordered(cr, t_min, best.t, t);
-            break;
-        }
-        default: h = hit_cylinder(q, r, t_min, best.t, t); break;
-        }
-        if (h) {
+        if (hit_any(q, r, t_min, best.t, t)) {
             best.t = t;
             best.slot = i;
         }
@@ -148,7 +151,7 @@ PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const
 // (cone.h:117-122 then tries the larger root first): its nearer root is taken only if an EARLIER
 // list entry already produced a hit nearer than the larger root.  Such a candidate is parked and
 // decided after the traversal when that is possible from what the traversal knows; otherwise the
-// ray is flagged and re-resolved by linear_nearest().
+// ray is flagged and its scan is replayed exactly over the few objects it can hit (bvh_exact_scan).
 // Where the traversal reads nodes and objects from.  GlobalSrc: the 64-B / 32-B records in HBM (cached
 // in L2 / Infinity Cache).  LdsSrc: a copy in the workgroup's LDS for scenes that fit, stored as float4
 // PLANES (quarter j of every node in plane j) so that the 64 lanes of one ds_read_b128 spread over all
@@ -181,9 +184,94 @@ struct LdsSrc {
     }
 };
 
-template <bool COUNT, int STRIDE, class Src>
+#define PT_SCAN_MAX 16 // candidates the exact replay keeps per ray
+
+// The list scan replayed exactly, for the rays whose answer depends on list order.  Whatever the
+// running t_max, the scan can only ever accept an object one of whose own roots lies in
+// [t_min, t_max] and passes its clip; one traversal WITHOUT nearest-hit pruning collects those
+// objects (a handful: the surfaces the ray really crosses), they are ordered by list index, and
+// hittable_list::hit (hittable_list.h:87-101) is replayed over them.  `overflow` is set when more
+// than PT_SCAN_MAX candidates exist (the caller then scans the whole list).
+template <int STRIDE, class Src>
+static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &src, uint32_t stack_cap, const Ray &r, const BoxRay &br, float t_min, float t_max,
+                               uint32_t *stack, bool &overflow)
+{
+    uint32_t ids[PT_SCAN_MAX], slots[PT_SCAN_MAX];
+    int n = 0;
+    overflow = false;
+    uint32_t sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            float4 a, b, c, d;
+            src.node(cur, a, b, c, d);
+            const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+            float tn0, tn1;
+            bool h0, h1;
+            box_test2(a, b, c, br, t_min, t_max, h0, h1, tn0, tn1);
+            if (h0 && h1) {
+                if (sp < stack_cap) stack[(sp++) * STRIDE] = (uint32_t)c1;
+                else overflow = true;
+                cur = c0;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            const uint32_t ref = (uint32_t)~cur, first = ref >> 3, count = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                float4 w0, w1;
+                src.prim(first + k, w0, w1);
+                PrimRec q;
+                q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                q.meta = __float_as_uint(w1.z);
+                q.id = __float_as_uint(w1.w);
+                float t;
+                bool possible;
+                if ((q.meta & 7u) == PT_CONE) {
+                    ConeRoots cr;
+                    possible = cone_roots(q, r, cr) &&
+                               ((!(cr.r1 < t_min || t_max < cr.r1) && cone_clip_ok(cr, cr.r1)) ||
+                                (!(cr.r2 < t_min || t_max < cr.r2) && cone_clip_ok(cr, cr.r2)));
+                } else {
+                    possible = hit_any(q, r, t_min, t_max, t);
+                }
+                if (possible) {
+                    if (n == PT_SCAN_MAX) { overflow = true; continue; }
+                    int at = n++;
+                    while (at > 0 && ids[at - 1] > q.id) { ids[at] = ids[at - 1]; slots[at] = slots[at - 1]; --at; }
+                    ids[at] = q.id;
+                    slots[at] = first + k;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = (int32_t)stack[(--sp) * STRIDE];
+    }
+    HitResult best;
+    best.t = t_max;
+    best.slot = PT_NO_PRIM;
+    for (int e = 0; e < n; ++e) { // hittable_list.h:92-98 over the candidates, in list order
+        float4 w0, w1;
+        src.prim(slots[e], w0, w1);
+        PrimRec q;
+        q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+        q.meta = __float_as_uint(w1.z);
+        q.id = __float_as_uint(w1.w);
+        float t;
+        if (hit_any(q, r, t_min, best.t, t)) {
+            best.t = t;
+            best.slot = slots[e];
+        }
+    }
+    return best;
+}
+
+// CONES = false compiles the cone case (and with it everything list-order dependent) out: the host
+// selects it for scenes that contain no cone.
+template <bool COUNT, bool CONES, int STRIDE, class Src>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
-                            uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim)
+                            uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay)
 {
     const BoxRay br = make_box_ray(r);
 
@@ -238,7 +326,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 case PT_CONE: {
                     ConeRoots cr;
                     h = false;
-                    if (cone_roots(q, r, cr)) {
+                    if (CONES && cone_roots(q, r, cr)) {
                         if (!(cr.a < 0.0f)) {
                             h = hit_cone_ordered(cr, t_min, best_t, t);
                         } else {
@@ -274,7 +362,8 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         cur = (int32_t)stack[(--sp) * STRIDE];
     }
 
-    if (n_pend > 1) need_exact = true;
+    if (!CONES) {
+    } else if (n_pend > 1) need_exact = true;
     else if (n_pend == 1 && !(best_t < pend_r2)) {
         // The parked cone is taken by the scan iff some EARLIER entry was accepted with t < pend_r1.
         if (best_slot != PT_NO_PRIM && best_t < pend_r1) {
@@ -290,7 +379,11 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     HitResult res;
     res.t = best_t;
     res.slot = best_slot;
-    return res;
+    if (CONES && need_exact) {
+        res = bvh_exact_scan<STRIDE>(src, stack_cap, r, br, t_min, t_max, stack, need_exact);
+        n_replay++;
+    }
+    return res; // need_exact still set: more candidates than the replay keeps, the caller scans the list
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,14 +430,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
             arr = sc.prims_list;
         } else {
             bool need_exact;
-            uint32_t nb = 0, np = 0;
+            uint32_t nb = 0, np = 0, nr = 0;
             GlobalSrc src{sc.nodes, sc.prims};
-            h = bvh_nearest<false, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+            h = bvh_nearest<false, true, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
             arr = sc.prims;
+            if (nr) {
+                flags = 2;
+                atomicAdd(&cnt->exact_replays, 1ull);
+            }
             if (need_exact) {
                 h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
                 arr = sc.prims_list;
-                flags = 1;
+                flags |= 1;
                 atomicAdd(&cnt->exact_fallbacks, 1ull);
             }
         }
@@ -417,7 +514,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(SceneDev sc, PassDev ps, Pa
 
 // Nearest hit for every queued ray.  LDS = true: the workgroup first copies the whole tree and object
 // array into LDS (scenes up to a few thousand objects) and traverses from there.
-template <bool COUNT, bool LDS, int BLOCK>
+template <bool COUNT, bool LDS, int BLOCK, bool CONES>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st, uint2 *__restrict__ hits,
                                                      const uint32_t *__restrict__ n_ptr, Counters *cnt)
 {
@@ -439,7 +536,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
     GlobalSrc gsrc{sc.nodes, sc.prims};
-    uint32_t nb = 0, np = 0, nf = 0;
+    uint32_t nb = 0, np = 0, nf = 0, nr = 0;
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
     for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
         uint32_t i = base + threadIdx.x;
@@ -450,10 +547,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         r.d = V(B.x, B.y, B.z);
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
-        else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
+        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         uint32_t slot = h.slot;
-        if (need_exact) {
+        if (CONES && need_exact) {
             // resolved on the list-order records; the top bit of the slot says which array it indexes
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             slot = h.slot == PT_NO_PRIM ? PT_NO_PRIM : (h.slot | 0x80000000u);
@@ -469,6 +566,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         }
     }
     if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
+    if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
 }
 
 // main.cu:59-64 for one hit: emitted(), scatter(), throughput.  Returns true when the path goes on
@@ -622,7 +720,7 @@ struct SliceDev {
     uint32_t *ticket;
 };
 
-template <bool COUNT, bool LDS, int BLOCK, bool SORT>
+template <bool COUNT, bool LDS, int BLOCK, bool SORT, bool CONES>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
     constexpr int WAVES = BLOCK / 64;
@@ -653,15 +751,15 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long rays = 0;
-    uint32_t nb = 0, np = 0, nf = 0;
+    uint32_t nb = 0, np = 0, nf = 0, nr = 0;
 
     // nearest hit of one ray; a list-order-resolved hit is returned with the top bit of the slot set
     auto trace = [&](const Ray &r) -> HitResult {
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
-        else h = bvh_nearest<COUNT, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np);
-        if (need_exact) {
+        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        if (CONES && need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
             nf++;
@@ -848,6 +946,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         }
     }
     if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
+    if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
 }
 
 // col += ray_color(...) in sample order (main.cu:93), and the pass's ray count.
@@ -888,6 +987,7 @@ struct pt_context {
     PrimRec *d_prims = nullptr, *d_prims_list = nullptr;
     float4 *d_mats = nullptr;
     uint32_t max_depth_tree = 0;
+    bool has_cones = false; // the scene holds at least one cone: the only object whose answer can depend on list order
     bool lds_scene = true; // traverse small scenes from LDS (PT_RENDER_NO_LDS_SCENE turns it off for A/B runs)
 
     // integrator workspace (grown on demand, kept across calls)
@@ -1101,6 +1201,8 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     }
     sc.cam.lens_radius = c.lens_radius;
     ctx->max_depth_tree = b.max_depth;
+    ctx->has_cones = false;
+    for (uint32_t i = 0; i < desc->n_prims; ++i) ctx->has_cones |= desc->prim_type[i] == PT_CONE;
     ctx->has_scene = true;
     return PT_OK;
 }
@@ -1126,16 +1228,16 @@ static void launch_intersect(pt_context *ctx, hipStream_t stream, const PathPlan
     if (lds_res) {
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min((max_paths + PT_ISECT_LDS_BLOCK - 1) / PT_ISECT_LDS_BLOCK, (size_t)ctx->n_cu * 2));
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK, true>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK, true>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     } else {
         const uint32_t grid = grid_for(ctx, max_paths);
         const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK, true>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK, true>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     }
 }
 
@@ -1237,16 +1339,21 @@ template <bool COUNT>
 static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
                          const PassDev &ps, const SliceDev &sl, float *d_rgb_sum)
 {
-#define PT_LAUNCH_PATHS(L, B, S) hipLaunchKernelGGL((k_paths<COUNT, L, B, S>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
-#define PT_LAUNCH_PATHS_S(L, B) do { if (sort) PT_LAUNCH_PATHS(L, B, true); else PT_LAUNCH_PATHS(L, B, false); } while (0)
+    const bool cones = ctx->has_cones;
+#define PT_LAUNCH_PATHS(L, B, S, C) hipLaunchKernelGGL((k_paths<COUNT, L, B, S, C>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_PATHS_SC(L, B)                                                 \
+    do {                                                                         \
+        if (sort) { if (cones) PT_LAUNCH_PATHS(L, B, true, true); else PT_LAUNCH_PATHS(L, B, true, false); }   \
+        else      { if (cones) PT_LAUNCH_PATHS(L, B, false, true); else PT_LAUNCH_PATHS(L, B, false, false); } \
+    } while (0)
     if (lds) {
-        if (block == 256) PT_LAUNCH_PATHS_S(true, 256);
-        else PT_LAUNCH_PATHS_S(true, 512);
+        if (block == 256) PT_LAUNCH_PATHS_SC(true, 256);
+        else PT_LAUNCH_PATHS_SC(true, 512);
     } else {
-        if (block == 256) PT_LAUNCH_PATHS_S(false, 256);
-        else PT_LAUNCH_PATHS_S(false, 512);
+        if (block == 256) PT_LAUNCH_PATHS_SC(false, 256);
+        else PT_LAUNCH_PATHS_SC(false, 512);
     }
-#undef PT_LAUNCH_PATHS_S
+#undef PT_LAUNCH_PATHS_SC
 #undef PT_LAUNCH_PATHS
 }
 
@@ -1328,6 +1435,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         stats->box_tests = h.box_tests;
         stats->prim_tests = h.prim_tests;
         stats->exact_fallbacks = h.exact_fallbacks;
+        stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_passes;
         stats->passes = n_passes;
         float ms = 0.0f;
@@ -1424,6 +1532,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
         stats->box_tests = h.box_tests;
         stats->prim_tests = h.prim_tests;
         stats->exact_fallbacks = h.exact_fallbacks;
+        stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_isect;
         stats->passes = n_passes;
         float ms = 0.0f;
