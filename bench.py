@@ -26,11 +26,11 @@ from pathtracer_amd import api, distributed, scenes  # noqa: E402
 # Workloads named by BASELINE.json's configs.  B / P: mean box and object tests per ray, measured
 # once with PT_RENDER_COUNT_TESTS on the library's tree (binned SAH, 16 bins, leaf <= 4) and frozen.
 WORKLOADS = {
-    "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50, B=3.59, P=2.40),
+    "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50, B=2.00, P=3.09),
     "c2": dict(name="random-spheres (485 spheres) 1920x1080 64spp depth50", scene=scenes.random_spheres_scene, w=1920, h=1080, spp=64, depth=50, B=16.78, P=4.01),
-    "c3": dict(name="cornell box 1024x1024 1024spp depth50", scene=scenes.cornell_scene, w=1024, h=1024, spp=1024, depth=50, B=6.0, P=7.0),
-    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50, B=60.0, P=5.0),
-    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50, B=70.0, P=5.0),
+    "c3": dict(name="cornell box 1024x1024 1024spp depth50", scene=scenes.cornell_scene, w=1024, h=1024, spp=1024, depth=50, B=3.98, P=4.85),
+    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50, B=59.21, P=7.23),
+    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50, B=73.95, P=8.18),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
 VALU_PEAK_TFLOPS = 78.6     # fp32 vector peak WITHOUT packed v_pk_fma (half of the 157.3 spec figure)
@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1984)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +97,10 @@ def main():
     ctx = api.Context(local_rank)
     ctx.upload(builder.desc())
     W, H, spp, depth = wl["w"], wl["h"], wl["spp"], wl["depth"]
+    name = wl["name"]
+    if args.spp > 0:
+        spp = args.spp
+        name += " [spp overridden to %d]" % spp
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     sample_offset, _ = distributed.weak_shard(rank, world, spp)
@@ -171,7 +176,7 @@ def main():
             "metric": "Mrays/s (incl. secondary bounces)", "value": rays_step * args.steps / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world,
+            "config": {"workload": name, "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world,
                        "max_depth": depth, "objects": int(len(builder.arrays()["prim_type"])), "rays_per_step": rays_step,
                        "parallelism": "spp-sharded x%d + all-reduce(sum) of the fp32 accumulation buffer" % world, "seed": args.seed},
             "roofline": roofline,
