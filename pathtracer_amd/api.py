@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
+LIB_PATH = os.environ.get("PT_LIB") or os.path.join(_HERE, "libpathtracer_amd.so")  # PT_LIB: a diagnostic build of the same ABI
 
 PT_OK = 0
 STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ERR_DEVICE", 4: "PT_ERR_LIMIT"}

@@ -51,6 +51,27 @@ struct PathPlanes {
 
 struct Counters { // device memory, zeroed per call
     unsigned long long rays, box_tests, prim_tests, exact_fallbacks, exact_replays;
+    // Diagnostics of a -DPT_SECTION_CLOCKS build only (k_paths): clock ticks per code section summed
+    // over waves, and active-lane / issued-lane slot counts of the three divergent loops.
+    unsigned long long sect[8];
+    unsigned long long lanes[4], slots[4];
+};
+
+#ifdef PT_SECTION_CLOCKS
+constexpr bool kProf = true;
+#else
+constexpr bool kProf = false;
+#endif
+struct ProfLanes { // per-lane tallies; slots are counted by the first active lane of each issue
+    uint32_t lanes[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0};
+    __device__ __forceinline__ void tick(int k)
+    {
+        if (kProf) {
+            const unsigned long long m = __ballot(true);
+            lanes[k] += 1;
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1)) slots[k] += 64;
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -112,7 +133,9 @@ PT_DI BoxRay make_box_ray(const Ray &r)
     const float dy = fabsf(r.d.y) < tiny ? copysignf(tiny, r.d.y) : r.d.y;
     const float dz = fabsf(r.d.z) < tiny ? copysignf(tiny, r.d.z) : r.d.z;
     BoxRay b;
-    b.ix = 1.0f / dx; b.iy = 1.0f / dy; b.iz = 1.0f / dz;
+    // the hardware reciprocal (1 ulp): both plane distances of an axis use the same value, so its error is
+    // a common relative factor 2^-23 on that axis' distances, inside the 2^-21 widening of box_test2
+    b.ix = __builtin_amdgcn_rcpf(dx); b.iy = __builtin_amdgcn_rcpf(dy); b.iz = __builtin_amdgcn_rcpf(dz);
     const float ox = r.o.x * b.ix, oy = r.o.y * b.iy, oz = r.o.z * b.iz;
     b.nox = -ox; b.noy = -oy; b.noz = -oz;
     b.eps = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * (1.0f / 4194304.0f); // 2^-22 * max|o*inv|: twice the rounding bound
@@ -121,8 +144,8 @@ PT_DI BoxRay make_box_ray(const Ray &r)
 
 // Conservative slab test of both child boxes (the role of aabb::hit, aabb.h:78-91).  It only prunes, so
 // its arithmetic is free-form: one FMA per plane distance.  Rounding can move a distance by at most
-// |o*inv| * 2^-24 absolutely and 2^-23 relatively, so the far end is widened by eps + 2^-21 relative
-// before the comparison.  A box the exact test accepts is therefore never rejected; a ray with a
+// |o*inv| * 2^-24 absolutely and 2^-23 (reciprocal) + 2^-24 (FMA) relatively, so the far end is widened
+// by eps + 2^-21 relative before the comparison (3 * 2^-23 needed for both ends together).  A box the exact test accepts is therefore never rejected; a ray with a
 // near-zero direction component has a huge eps and simply prunes less.
 PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const BoxRay &b, float t_min, float t_best,
                      bool &h0, bool &h1, float &tn0, float &tn1)
@@ -271,7 +294,8 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
 // selects it for scenes that contain no cone.
 template <bool COUNT, bool CONES, int STRIDE, class Src>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
-                            uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay)
+                            uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
+                            ProfLanes *prof = nullptr)
 {
     const BoxRay br = make_box_ray(r);
 
@@ -285,8 +309,11 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     uint32_t sp = 0;
     int32_t cur = 0; // root
     const uint32_t cap = stack_cap;
+    const int32_t done = INT32_MIN; // not a leaf reference: those are > INT32_MIN for fewer than 2^28 objects
     for (;;) {
-        if (cur >= 0) {
+        // Descend until this lane holds a leaf (or has nothing left); lanes that found theirs wait here, so
+        // that the expensive object tests below run with as many lanes of the wave as possible.
+        while (cur >= 0) {
             float4 a, b, c, d;
             src.node(cur, a, b, c, d);
             const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
@@ -294,17 +321,25 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
             bool h0, h1;
             box_test2(a, b, c, br, t_min, best_t, h0, h1, tn0, tn1);
             if (COUNT) n_box += 2;
+            if (kProf && prof) prof->tick(0);
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
                 int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
                 if (sp < cap) stack[(sp++) * STRIDE] = (uint32_t)farc;
                 else need_exact = true; // cannot happen: cap >= tree depth; never corrupt, re-resolve instead
                 cur = nearc;
-                continue;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else if (sp == 0) {
+                cur = done;
+            } else {
+                cur = (int32_t)stack[(--sp) * STRIDE];
             }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else {
+        }
+        if (cur == done) break;
+        {
             uint32_t ref = (uint32_t)~cur;
             uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
@@ -316,6 +351,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 q.meta = __float_as_uint(w1.z);
                 q.id = __float_as_uint(w1.w);
                 if (COUNT) n_prim += 1;
+                if (kProf && prof) prof->tick(1);
                 float t = 0.0f;
                 bool h;
                 switch (q.meta & 7u) {
@@ -574,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
 // emitted() is non-zero only for diffuse_light, whose scatter() returns false (material.h:295-304),
 // so a path's radiance is known exactly when it ends and is T * (emit | background | black).
 PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const Ray &r, v3 T, uint32_t pixel, uint32_t sample_abs,
-                     int32_t bounce, const PrimRec &q, float t, Ray &out_r, v3 &out_T, v3 &result)
+                     int32_t bounce, const PrimRec &q, float t, Ray &out_r, v3 &out_T, v3 &result, ProfLanes *prof = nullptr)
 {
     v3 p, normal;
     bool front;
@@ -606,6 +642,14 @@ PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const R
         scattered = true;
     } else {
         v3 rs = random_in_unit_sphere(g);
+        if (kProf && prof) { // tries of this lane against the tries the wave had to issue
+            const uint32_t tr = g.block;
+            uint32_t mx = 1;
+            while (__ballot(tr > mx)) ++mx;
+            const unsigned long long am = __ballot(true);
+            prof->lanes[2] += tr;
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)am) - 1)) prof->slots[2] += 64 * mx;
+        }
         atten = V(m.x, m.y, m.z);
         if (mtype == PT_LAMBERTIAN) { // material.h:90-99
             dir = vadd(normal, vunit(rs));
@@ -752,13 +796,23 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long rays = 0;
     uint32_t nb = 0, np = 0, nf = 0, nr = 0;
+    ProfLanes prof;
+    unsigned long long sect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = kProf ? clock64() : 0;
+    auto mark = [&](int k) {
+        if (kProf) {
+            const long long now = clock64();
+            sect[k] += (unsigned long long)(now - t_last);
+            t_last = now;
+        }
+    };
 
     // nearest hit of one ray; a list-order-resolved hit is returned with the top bit of the slot set
     auto trace = [&](const Ray &r) -> HitResult {
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
-        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
+        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
         if (CONES && need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
@@ -772,6 +826,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         if (threadIdx.x == 0) s_slice = atomicAdd(sl.ticket, 1u);
         __syncthreads();
         const uint32_t slice = s_slice;
+        mark(0);
         if (slice >= sl.n_slices) break;
         const uint32_t pix0 = slice * sl.pix_per_slice;
         const uint32_t npix = min(sl.pix_per_slice, ps.n_pixels - pix0);
@@ -780,6 +835,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         for (int32_t b = 0; b < ps.max_depth && in_count > 0; ++b) {
             if (threadIdx.x == 0) s_out[b & 1] = 0;
             __syncthreads();
+            mark(4);
             const float4 *inA = qA + cur * cap, *inB = qB + cur * cap;
             const float2 *inC = qC + cur * cap;
             float4 *outA = qA + (cur ^ 1u) * cap, *outB = qB + (cur ^ 1u) * cap;
@@ -800,7 +856,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         uint32_t s = lid / npix, pl = lid - s * npix;
                         Ray nr;
                         v3 nT;
-                        survive = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, b, q, h.t, nr, nT, result);
+                        if (kProf) prof.tick(3);
+                        survive = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, b, q, h.t, nr, nT, result, &prof);
                         if (survive) {
                             oA = make_float4(nr.o.x, nr.o.y, nr.o.z, __uint_as_float(lid));
                             oB = make_float4(nr.d.x, nr.d.y, nr.d.z, nT.x);
@@ -838,9 +895,12 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                     if (i < in_count) {
                         uint32_t s = i / npix, pl = i - s * npix;
                         r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
+                        mark(1);
                         h = trace(r);
                     }
+                    mark(2);
                     shade_emit(i < in_count, r, V(1.0f, 1.0f, 1.0f), i, h);
+                    mark(3);
                 } else if (!SORT) {
                     Ray r;
                     v3 T = V(0.0f, 0.0f, 0.0f);
@@ -855,9 +915,12 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         r.o = V(A.x, A.y, A.z);
                         r.d = V(B.x, B.y, B.z);
                         T = V(B.w, C.x, C.y);
+                        mark(1);
                         h = trace(r);
                     }
+                    mark(2);
                     shade_emit(i < in_count, r, T, lid, h);
+                    mark(3);
                 } else {
                     // Stage 1: nearest hit for the chunk's rays, in queue order.
                     uint32_t cls = 3; // 0 ends without random numbers (miss, light) | 1 glass | 2 diffuse, metal | 3 no ray
@@ -917,6 +980,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                 }
             }
             __syncthreads();
+            mark(4);
             if (threadIdx.x == 0) rays += in_count;
             in_count = s_out[b & 1];
             cur ^= 1u;
@@ -936,6 +1000,15 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
             rgb_sum[px + 1] = g;
             rgb_sum[px + 2] = bl;
         }
+        mark(5);
+    }
+    if (kProf) {
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long a = wave_sum_u32(prof.lanes[k]), b2 = wave_sum_u32(prof.slots[k]);
+            if (lane == 0) { atomicAdd(&cnt->lanes[k], a); atomicAdd(&cnt->slots[k], b2); }
+        }
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&cnt->sect[k], sect[k]);
     }
     if (threadIdx.x == 0 && rays) atomicAdd(&cnt->rays, rays);
     if (COUNT) {
@@ -1438,6 +1511,15 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_passes;
         stats->passes = n_passes;
+        if (kProf) {
+            static const char *names[6] = {"slice setup", "ray fetch / camera", "trace", "shade + emit", "bounce barriers", "film"};
+            unsigned long long tot = 0;
+            for (int k = 0; k < 6; ++k) tot += h.sect[k];
+            for (int k = 0; k < 6; ++k) fprintf(stderr, "[prof] %-20s %5.1f %% of wave time\n", names[k], 100.0 * (double)h.sect[k] / (double)std::max(tot, 1ull));
+            static const char *ln[4] = {"node visits", "object tests", "sphere-sample tries", "shade calls"};
+            for (int k = 0; k < 4; ++k)
+                fprintf(stderr, "[prof] %-20s lanes %llu slots %llu utilisation %.1f %%\n", ln[k], h.lanes[k], h.slots[k], 100.0 * (double)h.lanes[k] / (double)std::max(h.slots[k], 1ull));
+        }
         float ms = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
         stats->ms_total = ms;
