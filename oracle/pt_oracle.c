@@ -243,6 +243,10 @@ static int cone_hit(const float *q, v3 o, v3 d, float t_min, float t_max, orc_hi
     float normal_y = vlen(pc);
     outward.e[1] = normal_y * radius / height;
     set_face_normal(rec, d, outward);
+    /* A ray nearly parallel to the cone's side cancels the leading coefficient; the root is then
+     * rounding noise divided by a tiny a and can lie anywhere along the ray.  Such accepted hits are
+     * outside the parity contract (no bound on where they land), like NaN roots. */
+    rec->nan_flag = fabsf(a) < 0.015625f * (vlen2(dxz) + tangens * d.e[1] * d.e[1]) ? 2u : 0u;
     return 1;
 }
 
@@ -309,10 +313,12 @@ static int hit_list(const orc_scene *s, v3 o, v3 d, float t_min, float t_max, or
     uint32_t nan_flag = 0;
     memset(&temp, 0, sizeof temp);
     for (uint32_t i = 0; i < s->n_prims; ++i) {
+        temp.nan_flag = 0;
         if (hit_prim(s, i, o, d, t_min, closest_so_far, &temp)) {
             hit_anything = 1;
             closest_so_far = temp.t;
-            if (temp.t != temp.t) nan_flag = 1;
+            if (temp.t != temp.t) nan_flag |= 1;
+            nan_flag |= temp.nan_flag;
             *rec = temp;
             rec->prim = i;
         }

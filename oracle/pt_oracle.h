@@ -61,7 +61,8 @@ typedef struct orc_hit {
     float n[3];         /* face-forwarded normal (hit_record::normal) */
     uint32_t front;     /* hit_record::front_face */
     float p[3];
-    uint32_t nan_flag;  /* 1 when some object reported a NaN t for this ray (outside the parity contract) */
+    uint32_t nan_flag;  /* nonzero = outside the parity contract: bit 0 some object reported a NaN t for this ray,
+                         * bit 1 the scan accepted a cone hit whose quadratic's leading coefficient had cancelled */
 } orc_hit;
 
 /* camera.h:38-62 */

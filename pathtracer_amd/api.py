@@ -75,6 +75,27 @@ NODE_DTYPE = np.dtype([("lo", "<f4", (3, 2)), ("hi", "<f4", (3, 2)), ("c", "<i4"
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64 (same soname as /opt/rocm's, found through the
+    wheel's RPATH under another file name).  A process that loads this library first and torch second
+    ends up with two HIP runtimes, and the second one sees no GPU.  Loading the wheel's copy before
+    this library makes both resolve to that one runtime, whichever is imported first."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # the system runtime is used; importing torch later in this process will then fail to see the GPU
+
+
 def lib():
     """Loads the shared library; raises if it has not been built (no fallback exists)."""
     global _lib
@@ -84,6 +105,7 @@ def lib():
                 "libpathtracer_amd.so is missing (%s): build it with `make -C pathtracer_amd/csrc`; "
                 "there is no CPU fallback" % LIB_PATH
             )
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.pt_last_error.restype = C.c_char_p
         L.pt_last_error.argtypes = [C.c_void_p]

@@ -158,13 +158,15 @@ struct Builder {
 
 } // namespace
 
-bool prim_box(uint8_t type, const float *q, Box &b)
+bool prim_box(uint8_t type, const float *q, float kappa, Box &b)
 {
+    float extent = 0.0f; // quadrics: largest distance between the object's reference point and its surface
     const float pad_rect = 0.0001f; // aarect.h:48,147,232
     switch (type) {
     case PT_SPHERE: { // sphere.h:112-117 (|radius|: a negative radius would invert the reference's box)
         float r = std::fabs(q[3]);
         for (int a = 0; a < 3; ++a) { b.lo[a] = q[a] - r; b.hi[a] = q[a] + r; }
+        extent = r;
         break;
     }
     case PT_XY_RECT: // aarect.h:45-50
@@ -183,6 +185,7 @@ bool prim_box(uint8_t type, const float *q, Box &b)
         b.lo[0] = q[0] - r; b.hi[0] = q[0] + r;
         b.lo[2] = q[2] - r; b.hi[2] = q[2] + r;
         b.lo[1] = q[1]; b.hi[1] = q[1] + h;
+        extent = r + std::fabs(h);
         break;
     }
     default: return false;
@@ -195,9 +198,23 @@ bool prim_box(uint8_t type, const float *q, Box &b)
     }
     // The reference computes hit points in fp32 from coordinates of magnitude ~m, so an accepted
     // hit can sit a few ulp(m) outside the exact volume; 2^-17 * m is hundreds of ulps.
-    float pad = m * (1.0f / 131072.0f) + 1e-30f;
+    float pad = m * (1.0f / 131072.0f) + 1.01f * kappa * extent / (1.0f - kappa) + 1e-30f;
     for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
     return true;
+}
+
+float scene_kappa(const pt_scene_desc &d)
+{
+    float k = 1.0f / 1024.0f;
+    for (uint32_t i = 0; i < d.n_prims; ++i)
+        if (d.prim_type[i] == PT_CONE) {
+            const float tangens = std::fabs(d.prim_param[(size_t)i * 6 + 5]); // (radius/height)^2, cone.h:31
+            const float slope = std::sqrt(tangens);
+            const float kc = (1.0f / 256.0f) * (slope > 1.0f ? slope : 1.0f);
+            if (!(kc <= 1.0f / 16.0f)) return 1.0f / 16.0f;
+            k = std::max(k, kc);
+        }
+    return k;
 }
 
 std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
@@ -205,9 +222,10 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
     if (d.n_prims == 0) return "scene has no objects";
     if (d.n_prims >= (1u << 28)) return "too many objects (limit 2^28 - 1)";
     if (leaf_max < 1 || leaf_max > 8) return "leaf_max must be 1..8";
+    out.kappa = scene_kappa(d);
     std::vector<Box> boxes(d.n_prims);
     for (uint32_t i = 0; i < d.n_prims; ++i)
-        if (!prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, boxes[i]))
+        if (!prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, out.kappa, boxes[i]))
             return "object " + std::to_string(i) + " has an unknown tag or non-finite parameters";
     out.order.resize(d.n_prims);
     std::iota(out.order.begin(), out.order.end(), 0u);

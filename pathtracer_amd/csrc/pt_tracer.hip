@@ -37,6 +37,7 @@ struct SceneDev {
     const float4 *mats;
     uint32_t n_prims, n_nodes;
     uint32_t stack_cap; // entries per lane in the LDS traversal stack
+    float kappa;        // half-angle of the ray cone the slab test uses (pt::BvhBuild::kappa)
     DeviceCamera cam;
     float bg[3];
 };
@@ -116,53 +117,92 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
     return best;
 }
 
-// Per-ray constants of the slab test in FMA form: t = bound * inv - origin * inv.
+// The reference's hit arithmetic is fp32 on unnormalised rays, and what it ACCEPTS is not exactly the
+// geometry: a sphere at distance |oc| from the origin is hit when the computed discriminant
+// half_b^2 - a*c is >= 0, and that value carries a rounding error of up to 15 * 2^-24 * |oc|^2 |d|^2
+// (sphere.h:85-101: three-term dot products, the products, the subtraction).  The accepted root
+// therefore puts the ray point within sqrt(r^2 + eta^2) <= r + eta of the centre, eta =
+// sqrt(15 * 2^-24) |oc| = 9.5e-4 |oc|: far from the origin, small spheres are hit by rays that
+// geometrically miss them, and real hits land visibly outside the exact surface.  The same scaling
+// holds for the cylinder's quadratic (cylinder.h:96-123, two-term sums); rects only see rounding of
+// order 2^-23 (|o| + t|d|).  A tree that culled by exact geometry would lose such hits, so the slab
+// test treats the ray as a cone: a box is entered when some point o + t d comes within
+// kappa * |d| * t of it (per axis), kappa = 2^-10 > 9.5e-4 plus the lower-order terms.  (What |oc|
+// exceeds t|d| by -- the object's own extent -- is padded onto the boxes at build time.)
+//
+// Per axis x with w = kappa |d| / |d_x|, the condition  lo - kappa|d|t <= o + t d_x <= hi + kappa|d|t
+// is  t >= near / (1 + w)  and, when w < 1,  t <= far / (1 - w)  (no upper bound otherwise), with
+// near/far the plane distances (bound - o) / d_x.  Both are still one FMA per plane: the factors are
+// folded into per-ray constants  t = bound * A + C,  one pair for the plane that is the near one
+// for this ray's direction sign and one for the far one.
 struct BoxRay {
-    float ix, iy, iz;    // 1/d
-    float nox, noy, noz; // -(o * (1/d))
-    float eps;           // absolute error bound of t from rounding origin * inv
+    float alx, aly, alz, clx, cly, clz; // constants applied to a box's lo planes
+    float ahx, ahy, ahz, chx, chy, chz; // constants applied to its hi planes
+    float eps;                          // absolute error bound of a plane distance (rounding of o * inv)
 };
 
-PT_DI BoxRay make_box_ray(const Ray &r)
+PT_DI void box_ray_axis(float o, float d, float kd, float &a_lo, float &c_lo, float &a_hi, float &c_hi, float &cmax)
 {
-    // A component of exactly (or nearly) zero would make inv infinite and bound*inv - origin*inv a
-    // one-sided NaN; the box test sees such a ray as very slightly tilted instead (2^-60), which keeps
-    // every distance finite.  Only the pruning test sees this value; hit arithmetic uses the true ray.
+    // A component of exactly (or nearly) zero would make the reciprocal infinite; the box test sees such
+    // a ray as very slightly tilted instead (2^-60), which keeps every distance finite.  Only the pruning
+    // test sees this value; hit arithmetic uses the true ray.
     const float tiny = 8.6736174e-19f;
-    const float dx = fabsf(r.d.x) < tiny ? copysignf(tiny, r.d.x) : r.d.x;
-    const float dy = fabsf(r.d.y) < tiny ? copysignf(tiny, r.d.y) : r.d.y;
-    const float dz = fabsf(r.d.z) < tiny ? copysignf(tiny, r.d.z) : r.d.z;
+    const float dd = fabsf(d) < tiny ? copysignf(tiny, d) : d;
+    const float inv = __builtin_amdgcn_rcpf(dd);   // 1 ulp; the slack below covers it
+    const float w = kd * fabsf(inv);               // kappa |d| / |d_x|
+    const float g = __builtin_amdgcn_rcpf(1.0f + w) * 0.99999809f; // 1/(1+w), rounded down by 2^-19
+    const float no = -(o * inv);
+    const float a_n = inv * g, c_n = no * g;       // near plane
+    float a_f, c_f;
+    if (w < 0.99f) {
+        const float f = __builtin_amdgcn_rcpf(1.0f - w) * 1.00000191f; // 1/(1-w), rounded up by 2^-19
+        a_f = inv * f;
+        c_f = no * f;
+        cmax = fmaxf(cmax, fabsf(c_f));
+    } else { // the cone is wider than the ray's progress along this axis: no far bound from it
+        a_f = 0.0f;
+        c_f = 3.0e38f;
+    }
+    cmax = fmaxf(cmax, fabsf(c_n));
+    const bool pos = dd > 0.0f; // lo is the near plane
+    a_lo = pos ? a_n : a_f; c_lo = pos ? c_n : c_f;
+    a_hi = pos ? a_f : a_n; c_hi = pos ? c_f : c_n;
+}
+
+PT_DI BoxRay make_box_ray(const Ray &r, float kappa)
+{
     BoxRay b;
-    // the hardware reciprocal (1 ulp): both plane distances of an axis use the same value, so its error is
-    // a common relative factor 2^-23 on that axis' distances, inside the 2^-21 widening of box_test2
-    b.ix = __builtin_amdgcn_rcpf(dx); b.iy = __builtin_amdgcn_rcpf(dy); b.iz = __builtin_amdgcn_rcpf(dz);
-    const float ox = r.o.x * b.ix, oy = r.o.y * b.iy, oz = r.o.z * b.iz;
-    b.nox = -ox; b.noy = -oy; b.noz = -oz;
-    b.eps = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) * (1.0f / 4194304.0f); // 2^-22 * max|o*inv|: twice the rounding bound
+    // |d| from the hardware sqrt, rounded up: kd only has to be an upper bound of kappa |d|
+    const float kd = kappa * __builtin_amdgcn_sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z) * 1.000001f;
+    float cmax = 0.0f;
+    box_ray_axis(r.o.x, r.d.x, kd, b.alx, b.clx, b.ahx, b.chx, cmax);
+    box_ray_axis(r.o.y, r.d.y, kd, b.aly, b.cly, b.ahy, b.chy, cmax);
+    box_ray_axis(r.o.z, r.d.z, kd, b.alz, b.clz, b.ahz, b.chz, cmax);
+    b.eps = cmax * (1.0f / 4194304.0f); // 2^-22 * max|C|: twice the rounding bound of C and of bound * A near the origin
     return b;
 }
 
-// Conservative slab test of both child boxes (the role of aabb::hit, aabb.h:78-91).  It only prunes, so
-// its arithmetic is free-form: one FMA per plane distance.  Rounding can move a distance by at most
-// |o*inv| * 2^-24 absolutely and 2^-23 (reciprocal) + 2^-24 (FMA) relatively, so the far end is widened
-// by eps + 2^-21 relative before the comparison (3 * 2^-23 needed for both ends together).  A box the exact test accepts is therefore never rejected; a ray with a
-// near-zero direction component has a huge eps and simply prunes less.
+// Conservative slab test of both child boxes (the role of aabb::hit, aabb.h:78-91) against the ray's
+// cone.  It only prunes, so its arithmetic is free-form: one FMA per plane distance.  Rounding moves
+// a distance by at most eps absolutely and 2^-22 relatively (reciprocal 2^-23, constant 2^-24, FMA
+// 2^-24); the relative part is inside the 2^-19 by which the cone factors were rounded outwards.  A
+// box the exact test accepts is therefore never rejected.
 PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const BoxRay &b, float t_min, float t_best,
                      bool &h0, bool &h1, float &tn0, float &tn1)
 {
     // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z)
-    const float a0x = __builtin_fmaf(q0.x, b.ix, b.nox), a1x = __builtin_fmaf(q0.y, b.ix, b.nox);
-    const float a0y = __builtin_fmaf(q0.z, b.iy, b.noy), a1y = __builtin_fmaf(q0.w, b.iy, b.noy);
-    const float a0z = __builtin_fmaf(q1.x, b.iz, b.noz), a1z = __builtin_fmaf(q1.y, b.iz, b.noz);
-    const float b0x = __builtin_fmaf(q1.z, b.ix, b.nox), b1x = __builtin_fmaf(q1.w, b.ix, b.nox);
-    const float b0y = __builtin_fmaf(q2.x, b.iy, b.noy), b1y = __builtin_fmaf(q2.y, b.iy, b.noy);
-    const float b0z = __builtin_fmaf(q2.z, b.iz, b.noz), b1z = __builtin_fmaf(q2.w, b.iz, b.noz);
+    const float a0x = __builtin_fmaf(q0.x, b.alx, b.clx), a1x = __builtin_fmaf(q0.y, b.alx, b.clx);
+    const float a0y = __builtin_fmaf(q0.z, b.aly, b.cly), a1y = __builtin_fmaf(q0.w, b.aly, b.cly);
+    const float a0z = __builtin_fmaf(q1.x, b.alz, b.clz), a1z = __builtin_fmaf(q1.y, b.alz, b.clz);
+    const float b0x = __builtin_fmaf(q1.z, b.ahx, b.chx), b1x = __builtin_fmaf(q1.w, b.ahx, b.chx);
+    const float b0y = __builtin_fmaf(q2.x, b.ahy, b.chy), b1y = __builtin_fmaf(q2.y, b.ahy, b.chy);
+    const float b0z = __builtin_fmaf(q2.z, b.ahz, b.chz), b1z = __builtin_fmaf(q2.w, b.ahz, b.chz);
     tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), t_min));
     tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), t_min));
     const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), t_best));
     const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), t_best));
-    h0 = tn0 <= __builtin_fmaf(tf0, 1.00000048f, b.eps);
-    h1 = tn1 <= __builtin_fmaf(tf1, 1.00000048f, b.eps);
+    h0 = tn0 <= tf0 + b.eps;
+    h1 = tn1 <= tf1 + b.eps;
 }
 
 // Nearest hit through the BVH, with the list scan's semantics:
@@ -182,6 +222,7 @@ PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const
 struct GlobalSrc {
     const BvhNode *nodes;
     const PrimRec *prims;
+    float kappa; // half-angle of the ray cone the slab test uses (see make_box_ray)
     __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
     {
         const float4 *np = reinterpret_cast<const float4 *>(nodes + i);
@@ -197,6 +238,7 @@ struct LdsSrc {
     const float4 *nodes; // 4 planes of n_nodes
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
+    float kappa;
     __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
     {
         a = nodes[i]; b = nodes[n_nodes + i]; c = nodes[2 * n_nodes + i]; d = nodes[3 * n_nodes + i];
@@ -297,7 +339,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
                             ProfLanes *prof = nullptr)
 {
-    const BoxRay br = make_box_ray(r);
+    const BoxRay br = make_box_ray(r, src.kappa);
 
     float best_t = t_max;
     uint32_t best_slot = PT_NO_PRIM, best_id = 0;
@@ -467,7 +509,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
         } else {
             bool need_exact;
             uint32_t nb = 0, np = 0, nr = 0;
-            GlobalSrc src{sc.nodes, sc.prims};
+            GlobalSrc src{sc.nodes, sc.prims, sc.kappa};
             h = bvh_nearest<false, true, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
             arr = sc.prims;
             if (nr) {
@@ -558,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     const uint32_t n = *n_ptr;
     if (blockIdx.x * BLOCK >= n) return; // uniform per workgroup: nothing queued for it
     uint32_t *s_stack;
-    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims};
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.kappa};
     if (LDS) {
         float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
         s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
@@ -571,7 +613,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
-    GlobalSrc gsrc{sc.nodes, sc.prims};
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.kappa};
     uint32_t nb = 0, np = 0, nf = 0, nr = 0;
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
     for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
@@ -774,7 +816,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     __shared__ uint16_t s_perm[SORT ? BLOCK : 1];   // thread whose ray is shaded at each sorted position
     __shared__ uint16_t s_bin[SORT ? 4 * WAVES : 1]; // per (class, wave) counts, then exclusive offsets
     uint32_t *s_stack;
-    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims};
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.kappa};
     if (LDS) {
         float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
         s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
@@ -786,7 +828,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
-    GlobalSrc gsrc{sc.nodes, sc.prims};
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.kappa};
     const uint32_t cap = sl.cap;
     float4 *const qA = sl.qA + (size_t)blockIdx.x * 2 * cap;
     float4 *const qB = sl.qB + (size_t)blockIdx.x * 2 * cap;
@@ -1265,6 +1307,8 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     sc.n_prims = desc->n_prims;
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 1);
+    sc.kappa = b.kappa;
+    if (const char *kv = getenv("PT_KAPPA_SCALE")) sc.kappa *= (float)atof(kv); // diagnostic: < 1 voids the exactness guarantee
     const pt_camera &c = desc->camera;
     for (int k = 0; k < 3; ++k) {
         sc.cam.origin[k] = c.origin[k]; sc.cam.llc[k] = c.lower_left_corner[k];
