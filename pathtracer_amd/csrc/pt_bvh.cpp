@@ -210,7 +210,7 @@ float scene_kappa(const pt_scene_desc &d)
         if (d.prim_type[i] == PT_CONE) {
             const float tangens = std::fabs(d.prim_param[(size_t)i * 6 + 5]); // (radius/height)^2, cone.h:31
             const float slope = std::sqrt(tangens);
-            const float kc = (1.0f / 256.0f) * (slope > 1.0f ? slope : 1.0f);
+            const float kc = (1.0f / 512.0f) * (slope > 1.0f ? slope : 1.0f);
             if (!(kc <= 1.0f / 16.0f)) return 1.0f / 16.0f;
             k = std::max(k, kc);
         }

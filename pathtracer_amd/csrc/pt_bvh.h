@@ -30,9 +30,10 @@ struct BvhBuild {
 // How far outside an object's exact volume the reference's fp32 hit arithmetic can still report a hit,
 // as a fraction of the distance between ray origin and object: 2^-10 for spheres, cylinders and rects
 // (the discriminant of sphere.h:85-101 carries up to 15 * 2^-24 |oc|^2 |d|^2 of rounding error, i.e.
-// sqrt(15 * 2^-24) = 9.5e-4 |oc| in position).  A cone's quadratic (cone.h:101-112) mixes in
-// tangens-weighted y terms and cancels in its leading coefficient, so scenes with cones get
-// 2^-8 * max(1, radius/height), capped at 2^-4.
+// sqrt(15 * 2^-24) = 9.5e-4 |oc| in position; the largest displacement seen in stress runs is between
+// a quarter and a half of that).  A cone's quadratic (cone.h:101-112) mixes in tangens-weighted y
+// terms and cancels in its leading coefficient; no closed bound is derived for it, and scenes with
+// cones get 2^-9 * max(1, radius/height), capped at 2^-4 (stress runs need less than 2^-12).
 float scene_kappa(const pt_scene_desc &desc);
 
 // Bounding volume of one object as the reference defines it (sphere.h:112-117, aarect.h:45-50,

@@ -144,6 +144,62 @@ def test_degenerate_objects(ctx):
     assert st["rays"] == rays and frac < 2e-3 and rmse < 2e-3
 
 
+def _far_field(kind, n, rng, center):
+    b = scenes.SceneBuilder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    c = center + (rng.random((n, 3)) - 0.5) * 60
+    for k in range(n):
+        r = 0.05 + rng.random() * 0.4
+        what = kind if kind != "mixed" else ("sphere", "cyl", "cone", "rect")[k % 4]
+        if what == "sphere":
+            b.sphere(c[k], r, m)
+        elif what == "cyl":
+            b.cylinder2(c[k], 0.2 + rng.random(), r, m)
+        elif what == "cone":
+            b.cone(c[k], 0.3 + rng.random(), r, m)
+        else:
+            lo, hi = c[k] - r, c[k] + r
+            if k // 4 % 3 == 0:
+                b.xy_rect(lo[0], hi[0], lo[1], hi[1], c[k][2], m)
+            elif k // 4 % 3 == 1:
+                b.xz_rect(lo[0], hi[0], lo[2], hi[2], c[k][1], m)
+            else:
+                b.yz_rect(lo[1], hi[1], lo[2], hi[2], c[k][0], m)
+    b.camera(tuple(center + [0, 0, 100]), tuple(center), (0, 1, 0), 40.0, 1.0, 0.0, 100.0)
+    return b, c
+
+
+@pytest.mark.parametrize("kind", ["sphere", "mixed"])
+@pytest.mark.parametrize("center", [(0.0, 0.0, 0.0), (5000.0, 300.0, -2000.0)])
+def test_far_field_hits_outside_the_exact_surface(ctx, kind, center):
+    """Small objects seen from 10..3000 units away along unnormalised directions of length 0.1..300: the
+    reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) then accept roots
+    whose points lie visibly outside the exact surfaces, or hit objects the ray geometrically misses.
+    The tree must not cull them: every hit is still the scan's, bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    n, nr = 1500, 60000
+    b, c = _far_field(kind, n, rng, np.asarray(center))
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    tgt = c[rng.integers(0, n, nr)] + (rng.random((nr, 3)) - 0.5) * 1.2
+    dist = 10 ** (1 + rng.random(nr) * 2.5)
+    dirn = rng.standard_normal((nr, 3))
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    o = (tgt - dirn * dist[:, None]).astype(np.float32)
+    d = (dirn * (10 ** (rng.random(nr) * 3.5 - 1))[:, None]).astype(np.float32)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d)
+    ok = ref["nan_flag"] == 0
+    bad = util.hits_equal(got, ref) & ok
+    assert not bad.any(), (kind, center, int(bad.sum()))
+    assert ok.mean() > 0.99 and (ref["prim"] != api.NO_PRIM).sum() > 5000
+    if kind == "sphere":  # the regime is exercised: hit points well outside the exact spheres do occur
+        hit = ref["prim"] != api.NO_PRIM
+        a = b.arrays()["prim_param"][ref["prim"][hit]]
+        excess = np.linalg.norm(ref["p"][hit].astype(np.float64) - a[:, :3], axis=1) - a[:, 3]
+        assert (excess > 0.05 * a[:, 3]).sum() > 50
+
+
 # ------------------------------------------------------------------------------------------------
 # shapes and sizes
 # ------------------------------------------------------------------------------------------------
