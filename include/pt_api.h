@@ -73,7 +73,7 @@ typedef struct pt_hit {
     uint32_t flags; /* bit 1: list-order dependent, replayed over the ray's candidate objects; bit 0: resolved by the full list scan */
 } pt_hit;
 
-enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1 };
+enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1, PT_TRACE_BVH_IN_SCENE = 2 };
 
 typedef struct pt_render_params {
     int32_t width, height;
@@ -125,7 +125,11 @@ pt_status pt_camera_look_at(const float lookfrom[3], const float lookat[3], cons
 pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc);
 
 /* hittable_list::hit (hittable_list.h:87-101) for n rays.  o_xyz / d_xyz / out are host buffers.
- * mode PT_TRACE_BVH is the production traversal, PT_TRACE_LINEAR the list-order scan on the GPU. */
+ * mode PT_TRACE_BVH is the production traversal, PT_TRACE_LINEAR the list-order scan on the GPU.
+ * PT_TRACE_BVH_IN_SCENE is the traversal exactly as pt_render runs it: the caller asserts that every
+ * origin lies within the scene's bounds extended to the camera (as a render's origins do), which lets
+ * the traversal narrow its conservative ray cone; with origins outside, hits far from the origin
+ * may be lost.  All three give the same answers where their preconditions hold. */
 pt_status pt_trace_rays(pt_context *ctx, const float *o_xyz, const float *d_xyz, size_t n, float t_min, float t_max,
                         int mode, pt_hit *out);
 /* Same with device pointers, enqueued on `stream` (a hipStream_t; NULL = the default stream). */

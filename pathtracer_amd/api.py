@@ -16,7 +16,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ER
 
 SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
-TRACE_BVH, TRACE_LINEAR = 0, 1
+TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE = 0, 1, 2
 RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS = 1, 2, 4, 8, 16
 NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)

@@ -158,7 +158,7 @@ struct Builder {
 
 } // namespace
 
-bool prim_box(uint8_t type, const float *q, float kappa, Box &b)
+bool prim_box(uint8_t type, const float *q, float kappa, float extra, Box &b)
 {
     float extent = 0.0f; // quadrics: largest distance between the object's reference point and its surface
     const float pad_rect = 0.0001f; // aarect.h:48,147,232
@@ -198,23 +198,9 @@ bool prim_box(uint8_t type, const float *q, float kappa, Box &b)
     }
     // The reference computes hit points in fp32 from coordinates of magnitude ~m, so an accepted
     // hit can sit a few ulp(m) outside the exact volume; 2^-17 * m is hundreds of ulps.
-    float pad = m * (1.0f / 131072.0f) + 1.01f * kappa * extent / (1.0f - kappa) + 1e-30f;
+    float pad = m * (1.0f / 131072.0f) + 1.01f * kappa * extent / (1.0f - kappa) + extra + 1e-30f;
     for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
     return true;
-}
-
-float scene_kappa(const pt_scene_desc &d)
-{
-    float k = 1.0f / 1024.0f;
-    for (uint32_t i = 0; i < d.n_prims; ++i)
-        if (d.prim_type[i] == PT_CONE) {
-            const float tangens = std::fabs(d.prim_param[(size_t)i * 6 + 5]); // (radius/height)^2, cone.h:31
-            const float slope = std::sqrt(tangens);
-            const float kc = (1.0f / 512.0f) * (slope > 1.0f ? slope : 1.0f);
-            if (!(kc <= 1.0f / 16.0f)) return 1.0f / 16.0f;
-            k = std::max(k, kc);
-        }
-    return k;
 }
 
 std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
@@ -222,11 +208,72 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
     if (d.n_prims == 0) return "scene has no objects";
     if (d.n_prims >= (1u << 28)) return "too many objects (limit 2^28 - 1)";
     if (leaf_max < 1 || leaf_max > 8) return "leaf_max must be 1..8";
-    out.kappa = scene_kappa(d);
+    ConeParams &cp = out.cone;
+    cp = ConeParams();
     std::vector<Box> boxes(d.n_prims);
-    for (uint32_t i = 0; i < d.n_prims; ++i)
-        if (!prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, out.kappa, boxes[i]))
+    // exact volumes first: the scene's extent decides which objects can carry their own padding
+    Box root;
+    box_empty(root);
+    bool any_quadric = false, any_cone = false;
+    float cone_slope = 1.0f;
+    for (uint32_t i = 0; i < d.n_prims; ++i) {
+        const float *q = d.prim_param + (size_t)i * 6;
+        if (!prim_box(d.prim_type[i], q, 0.0f, 0.0f, boxes[i]))
             return "object " + std::to_string(i) + " has an unknown tag or non-finite parameters";
+        box_grow(root, boxes[i]);
+        if (d.prim_type[i] == PT_SPHERE || d.prim_type[i] == PT_CYLINDER) any_quadric = true;
+        if (d.prim_type[i] == PT_CONE) {
+            any_cone = true;
+            cone_slope = std::max(cone_slope, std::sqrt(std::fabs(q[5]))); // tangens = (radius/height)^2, cone.h:31
+        }
+    }
+    const float k_quad = 1.0f / 1024.0f, k_round = 1.0f / 1048576.0f;
+    std::vector<float> extra(d.n_prims, 0.0f);
+    if (any_cone) {
+        cp.kappa_max = (1.0f / 512.0f) * cone_slope;
+        if (!(cp.kappa_max <= 1.0f / 16.0f)) cp.kappa_max = 1.0f / 16.0f;
+        cp.kappa_min = cp.kappa_max;
+    } else if (!any_quadric) {
+        cp.kappa_max = cp.kappa_min = k_round;
+    } else {
+        cp.kappa_max = k_quad;
+        cp.kappa_min = k_round;
+        cp.adaptive = 1;
+        Box ext = root; // ray origins of a render: the camera and points on the objects
+        for (int a = 0; a < 3; ++a) {
+            ext.lo[a] = std::min(ext.lo[a], d.camera.origin[a]);
+            ext.hi[a] = std::max(ext.hi[a], d.camera.origin[a]);
+        }
+        double diag2 = 0;
+        for (int a = 0; a < 3; ++a) diag2 += ((double)ext.hi[a] - ext.lo[a]) * ((double)ext.hi[a] - ext.lo[a]);
+        const double reach = 1.05 * std::sqrt(diag2) + 1e-3; // no origin in `ext` (grown below) is farther from any object
+        Box dyn;
+        box_empty(dyn);
+        for (uint32_t i = 0; i < d.n_prims; ++i) {
+            if (d.prim_type[i] != PT_SPHERE && d.prim_type[i] != PT_CYLINDER) continue;
+            const float *q = d.prim_param + (size_t)i * 6;
+            const double r = std::fabs(d.prim_type[i] == PT_SPHERE ? q[3] : q[4]);
+            const double eta = (double)k_quad * reach;
+            const double f = eta * eta / (std::sqrt(r * r + eta * eta) + r);
+            if (f <= r / 256.0) {
+                extra[i] = (float)(1.01 * f);
+            } else {
+                cp.r_min = std::min(cp.r_min, (float)r);
+                box_grow(dyn, boxes[i]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            const float grow = (float)(0.01 * reach) + std::fabs(d.camera.lens_radius);
+            cp.elo[a] = ext.lo[a] - grow;
+            cp.ehi[a] = ext.hi[a] + grow;
+            if (dyn.lo[a] <= dyn.hi[a]) {
+                cp.qc[a] = 0.5f * dyn.lo[a] + 0.5f * dyn.hi[a];
+                cp.qh += (0.5f * (dyn.hi[a] - dyn.lo[a])) * 1.000001f + 1e-30f;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < d.n_prims; ++i) // an object that carries its own padding needs no share of the cone's
+        prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, extra[i] > 0.0f ? 0.0f : cp.kappa_max, extra[i], boxes[i]);
     out.order.resize(d.n_prims);
     std::iota(out.order.begin(), out.order.end(), 0u);
     out.nodes.clear();

@@ -37,7 +37,7 @@ struct SceneDev {
     const float4 *mats;
     uint32_t n_prims, n_nodes;
     uint32_t stack_cap; // entries per lane in the LDS traversal stack
-    float kappa;        // half-angle of the ray cone the slab test uses (pt::BvhBuild::kappa)
+    pt::ConeParams cone; // how wide a cone the slab test gives a ray
     DeviceCamera cam;
     float bg[3];
 };
@@ -169,6 +169,20 @@ PT_DI void box_ray_axis(float o, float d, float kd, float &a_lo, float &c_lo, fl
     a_hi = pos ? a_f : a_n; c_hi = pos ? c_f : c_n;
 }
 
+// Slope of the cone for a ray from origin o (pt::ConeParams): the chord slope f(Dm) / Dm of the excess
+// function of the smallest object that relies on the cone, f(D) = sqrt(r^2 + k^2 D^2) - r, that is
+// k * eta / (sqrt(r^2 + eta^2) + r) with eta = k Dm.  Dm is the largest distance from o to the bounds
+// of those objects, taken in the L1 norm, and the square root is replaced by max(r, eta) below it:
+// both only widen the cone.
+PT_DI float ray_kappa(const pt::ConeParams &cp, v3 o)
+{
+    if (!cp.adaptive) return cp.kappa_max;
+    const float d1 = (fabsf(o.x - cp.qc[0]) + fabsf(o.y - cp.qc[1])) + (fabsf(o.z - cp.qc[2]) + cp.qh);
+    const float eta = cp.kappa_max * d1;
+    const float kq = (cp.kappa_max * 1.00001f) * eta * __builtin_amdgcn_rcpf(fmaxf(cp.r_min, eta) + cp.r_min);
+    return fminf(fmaxf(kq, cp.kappa_min), cp.kappa_max); // no such objects: r_min is huge and kq = 0
+}
+
 PT_DI BoxRay make_box_ray(const Ray &r, float kappa)
 {
     BoxRay b;
@@ -222,7 +236,7 @@ PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const
 struct GlobalSrc {
     const BvhNode *nodes;
     const PrimRec *prims;
-    float kappa; // half-angle of the ray cone the slab test uses (see make_box_ray)
+    pt::ConeParams cone;
     __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
     {
         const float4 *np = reinterpret_cast<const float4 *>(nodes + i);
@@ -238,7 +252,7 @@ struct LdsSrc {
     const float4 *nodes; // 4 planes of n_nodes
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
-    float kappa;
+    pt::ConeParams cone;
     __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
     {
         a = nodes[i]; b = nodes[n_nodes + i]; c = nodes[2 * n_nodes + i]; d = nodes[3 * n_nodes + i];
@@ -339,7 +353,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
                             ProfLanes *prof = nullptr)
 {
-    const BoxRay br = make_box_ray(r, src.kappa);
+    const BoxRay br = make_box_ray(r, ray_kappa(src.cone, r.o));
 
     float best_t = t_max;
     uint32_t best_slot = PT_NO_PRIM, best_id = 0;
@@ -509,7 +523,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
         } else {
             bool need_exact;
             uint32_t nb = 0, np = 0, nr = 0;
-            GlobalSrc src{sc.nodes, sc.prims, sc.kappa};
+            GlobalSrc src{sc.nodes, sc.prims, sc.cone};
+            if (MODE != PT_TRACE_BVH_IN_SCENE) src.cone.adaptive = 0; // origins from outside the scene's bounds: widest cone
             h = bvh_nearest<false, true, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
             arr = sc.prims;
             if (nr) {
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     const uint32_t n = *n_ptr;
     if (blockIdx.x * BLOCK >= n) return; // uniform per workgroup: nothing queued for it
     uint32_t *s_stack;
-    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.kappa};
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.cone};
     if (LDS) {
         float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
         s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
-    GlobalSrc gsrc{sc.nodes, sc.prims, sc.kappa};
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.cone};
     uint32_t nb = 0, np = 0, nf = 0, nr = 0;
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
     for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
@@ -816,7 +831,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     __shared__ uint16_t s_perm[SORT ? BLOCK : 1];   // thread whose ray is shaded at each sorted position
     __shared__ uint16_t s_bin[SORT ? 4 * WAVES : 1]; // per (class, wave) counts, then exclusive offsets
     uint32_t *s_stack;
-    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.kappa};
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.cone};
     if (LDS) {
         float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
         s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
-    GlobalSrc gsrc{sc.nodes, sc.prims, sc.kappa};
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.cone};
     const uint32_t cap = sl.cap;
     float4 *const qA = sl.qA + (size_t)blockIdx.x * 2 * cap;
     float4 *const qB = sl.qB + (size_t)blockIdx.x * 2 * cap;
@@ -1127,6 +1142,12 @@ struct pt_context {
     std::vector<hipEvent_t> events;
 };
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static pt_status fail(pt_context *ctx, pt_status st, const std::string &msg)
 {
     if (ctx) ctx->err = msg;
@@ -1307,8 +1328,12 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     sc.n_prims = desc->n_prims;
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 1);
-    sc.kappa = b.kappa;
-    if (const char *kv = getenv("PT_KAPPA_SCALE")) sc.kappa *= (float)atof(kv); // diagnostic: < 1 voids the exactness guarantee
+    sc.cone = b.cone;
+    if (const char *kv = getenv("PT_KAPPA_SCALE")) { // diagnostic: < 1 voids the exactness guarantee
+        sc.cone.kappa_max *= (float)atof(kv);
+        sc.cone.kappa_min *= (float)atof(kv);
+    }
+    if (env_int("PT_KAPPA_ADAPTIVE", 1) == 0) sc.cone.adaptive = 0; // diagnostic: every ray gets kappa_max
     const pt_camera &c = desc->camera;
     for (int k = 0; k < 3; ++k) {
         sc.cam.origin[k] = c.origin[k]; sc.cam.llc[k] = c.lower_left_corner[k];
@@ -1365,7 +1390,7 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
     if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return PT_OK;
     if (!d_o || !d_d || !d_out) return fail(ctx, PT_ERR_INVALID, "null ray or output buffer");
-    if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
+    if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR && mode != PT_TRACE_BVH_IN_SCENE) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
@@ -1373,6 +1398,8 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
     size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
     if (mode == PT_TRACE_LINEAR)
         hipLaunchKernelGGL(k_trace<PT_TRACE_LINEAR>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
+    else if (mode == PT_TRACE_BVH_IN_SCENE)
+        hipLaunchKernelGGL(k_trace<PT_TRACE_BVH_IN_SCENE>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
     else
         hipLaunchKernelGGL(k_trace<PT_TRACE_BVH>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
     PT_HIP(ctx, hipGetLastError());
@@ -1446,11 +1473,6 @@ struct StageTimer {
     void end() { if (on) hipEventRecord(get(), stream); }
 };
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 template <bool COUNT>
 static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,

@@ -29,7 +29,7 @@ def _image_close(got, ref):
 # committed fixtures (no oracle call: these run from the files alone)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", list(SCENES))
-@pytest.mark.parametrize("mode", [api.TRACE_BVH, api.TRACE_LINEAR])
+@pytest.mark.parametrize("mode", [api.TRACE_BVH, api.TRACE_LINEAR, api.TRACE_BVH_IN_SCENE])
 def test_golden_ray_batches(ctx, name, mode):
     g = np.load(os.path.join(GOLD, "rays_%s.npz" % name))
     ctx.upload(SCENES[name]().desc())
@@ -169,16 +169,22 @@ def _far_field(kind, n, rng, center):
     return b, c
 
 
-@pytest.mark.parametrize("kind", ["sphere", "mixed"])
+@pytest.mark.parametrize("kind", ["sphere", "mixed", "sphere enclosed", "cyl enclosed"])
 @pytest.mark.parametrize("center", [(0.0, 0.0, 0.0), (5000.0, 300.0, -2000.0)])
 def test_far_field_hits_outside_the_exact_surface(ctx, kind, center):
     """Small objects seen from 10..3000 units away along unnormalised directions of length 0.1..300: the
     reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) then accept roots
     whose points lie visibly outside the exact surfaces, or hit objects the ray geometrically misses.
-    The tree must not cull them: every hit is still the scan's, bit for bit."""
+    The tree must not cull them: every hit is still the scan's, bit for bit.  The "enclosed" variants put
+    a sphere of radius 4000 around everything, so that the origins lie within the scene's bounds, and trace
+    as the render does (ray cone narrowed per origin)."""
     rng = np.random.Generator(np.random.PCG64(11))
     n, nr = 1500, 60000
+    enclosed = kind.endswith(" enclosed")
+    kind = kind.split()[0]
     b, c = _far_field(kind, n, rng, np.asarray(center))
+    if enclosed:
+        b.sphere(center, 4000.0, 0)
     ctx.upload(b.desc())
     osc = util.oracle_scene(b)
     tgt = c[rng.integers(0, n, nr)] + (rng.random((nr, 3)) - 0.5) * 1.2
@@ -188,13 +194,13 @@ def test_far_field_hits_outside_the_exact_surface(ctx, kind, center):
     o = (tgt - dirn * dist[:, None]).astype(np.float32)
     d = (dirn * (10 ** (rng.random(nr) * 3.5 - 1))[:, None]).astype(np.float32)
     ref = osc.trace(o, d)
-    got = ctx.trace(o, d)
+    got = ctx.trace(o, d, mode=api.TRACE_BVH_IN_SCENE if enclosed else api.TRACE_BVH)
     ok = ref["nan_flag"] == 0
     bad = util.hits_equal(got, ref) & ok
     assert not bad.any(), (kind, center, int(bad.sum()))
-    assert ok.mean() > 0.99 and (ref["prim"] != api.NO_PRIM).sum() > 5000
+    assert ok.mean() > 0.99 and ((ref["prim"] != api.NO_PRIM) & (ref["prim"] < n)).sum() > 5000
     if kind == "sphere":  # the regime is exercised: hit points well outside the exact spheres do occur
-        hit = ref["prim"] != api.NO_PRIM
+        hit = (ref["prim"] != api.NO_PRIM) & (ref["prim"] < n)
         a = b.arrays()["prim_param"][ref["prim"][hit]]
         excess = np.linalg.norm(ref["p"][hit].astype(np.float64) - a[:, :3], axis=1) - a[:, 3]
         assert (excess > 0.05 * a[:, 3]).sum() > 50
@@ -275,12 +281,13 @@ def test_large_scene_trace_bit_exact(ctx, which):
     osc = util.oracle_scene(b)
     o, d = util.mixed_rays(b, osc, n, seed=55)
     ref = osc.trace(o, d)
-    got = ctx.trace(o, d)
     ok = ref["nan_flag"] == 0
-    bad = util.hits_equal(got, ref) & ok
-    assert not bad.any(), (which, int(bad.sum()))
+    for mode in (api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
+        got = ctx.trace(o, d, mode=mode)
+        bad = util.hits_equal(got, ref) & ok
+        assert not bad.any(), (which, mode, int(bad.sum()))
+        assert (got["flags"] & 1).sum() == 0  # no ray needed the full list scan
     assert (ref["prim"] != api.NO_PRIM).mean() > 0.2
-    assert (got["flags"] & 1).sum() == 0  # no ray needed the full list scan
 
 
 def test_large_scene_render_crop(ctx):

@@ -33,11 +33,14 @@ def loaded(request, ctx):
     return request.param, b, util.oracle_scene(b)
 
 
-def test_trace_bvh_bit_exact(loaded, ctx):
+@pytest.mark.parametrize("mode", [api.TRACE_BVH, api.TRACE_BVH_IN_SCENE])
+def test_trace_bvh_bit_exact(loaded, ctx, mode):
+    """TRACE_BVH_IN_SCENE is the traversal as the render runs it (ray cone narrowed by the scene's bounds);
+    these batches start at the camera, on the objects or between them, as a render's rays do."""
     name, b, osc = loaded
     o, d = util.mixed_rays(b, osc, 20000, seed=101)
     ref = osc.trace(o, d)
-    got = ctx.trace(o, d, mode=api.TRACE_BVH)
+    got = ctx.trace(o, d, mode=mode)
     ok = ref["nan_flag"] == 0
     bad = util.hits_equal(got, ref) & ok
     assert ok.mean() > 0.999
