@@ -290,15 +290,19 @@ def test_large_scene_trace_bit_exact(ctx, which):
     assert (ref["prim"] != api.NO_PRIM).mean() > 0.2
 
 
-def test_large_scene_render_crop(ctx):
-    """BASELINE config 4's scene at 4K, 1 spp: a crop against the oracle and equal ray statistics for
-    the crop's paths (through finite images and sane counters for the full frame)."""
-    b = scenes.mixed_scene()
+@pytest.mark.parametrize("which", ["mixed_100k", "spheres_1m"])
+def test_large_scene_render_crop(ctx, which):
+    """BASELINE configs 4 and 5: their scenes at 4K, 1 spp; a crop against the oracle (which renders only
+    those pixels: the stream is keyed by the absolute pixel index), finite images and sane counters for
+    the full frame."""
+    if which == "mixed_100k":
+        b, (x0, y0, w, h) = scenes.mixed_scene(), (1900, 1100, 24, 12)
+    else:
+        b, (x0, y0, w, h) = scenes.sphere_slab_scene(), (1912, 1500, 12, 6)
     ctx.upload(b.desc())
     osc = util.oracle_scene(b)
     got, st = ctx.render(3840, 2160, 1, 50)
-    x0, y0, w, h = 1900, 1100, 24, 12
     ref, _ = osc.render(3840, 2160, 1, 50, region=(x0, y0, w, h))
     frac, rmse = _image_close(got[y0:y0 + h, x0:x0 + w], ref)
-    assert frac <= 0.01 and rmse < 5e-3, (frac, rmse)
+    assert frac <= 0.015 and rmse < 5e-3, (which, frac, rmse)
     assert np.isfinite(got).all() and st["exact_fallbacks"] == 0 and st["rays"] > st["primary_rays"]
