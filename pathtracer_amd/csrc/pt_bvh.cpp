@@ -230,7 +230,7 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
     const float k_quad = 1.0f / 1024.0f, k_round = 1.0f / 1048576.0f;
     std::vector<float> extra(d.n_prims, 0.0f);
     if (any_cone) {
-        cp.kappa_max = (1.0f / 512.0f) * cone_slope;
+        cp.kappa_max = k_quad * cone_slope;
         if (!(cp.kappa_max <= 1.0f / 16.0f)) cp.kappa_max = 1.0f / 16.0f;
         cp.kappa_min = cp.kappa_max;
     } else if (!any_quadric) {

@@ -38,8 +38,9 @@ struct Box {
 // enter r_min or the cluster bounds.
 //
 // A cone's quadratic (cone.h:101-112) mixes in tangens-weighted y terms and cancels in its leading
-// coefficient; no closed bound is derived for it.  Scenes with cones use a fixed slope of
-// 2^-9 * max(1, radius/height), capped at 2^-4 (stress runs need less than 2^-12).
+// coefficient (worst-case analysis gives sqrt(31 * 2^-24 / psi) of the tangens-weighted distance, psi the
+// surviving fraction of that coefficient: no useful closed bound).  Scenes with cones use a fixed slope
+// of 2^-10 * max(1, radius/height), capped at 2^-4; stress runs need less than a quarter of it.
 struct ConeParams {
     float kappa_max = 0.0f;   // slope that is sufficient for any ray
     float kappa_min = 0.0f;   // rounding-level slope every ray gets at least

@@ -1519,7 +1519,11 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
 
-    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", 32768));
+    // Paths per slice: 32k amortises a slice's ramp-down best, but a frame needs a few slices per resident
+    // workgroup to balance (a slice's cost varies several-fold with what its pixels see).
+    const uint64_t total_paths = (uint64_t)n_pixels * pr->spp;
+    const uint32_t balanced = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(4096, total_paths / (4ull * grid_max)));
+    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", (int)balanced));
     uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
     spass = std::min(spass, pr->spp);
     uint32_t pix = std::max(64u, (target / spass) & ~63u);
