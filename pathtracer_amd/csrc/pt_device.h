@@ -95,7 +95,11 @@ PT_DI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
         const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // a ^ b ^ key in one instruction: gfx950's three-input boolean op with truth table 0x96, the
+        // (wave-uniform) round key as its scalar operand
+        uint32_t n0, n2;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"(hi1), "v"(c1), "s"(k0));
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"(hi0), "v"(c3), "s"(k1));
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
     }
@@ -114,15 +118,22 @@ PT_DI void rng_block(Rng &g, float u[4])
     for (int i = 0; i < 4; ++i) u[i] = u32_to_uniform(o[i]);
 }
 
+// 2u - 1 for the uniform u = ((x >> 8) + 1) * 2^-24 that u32_to_uniform() makes of a random word, as the
+// samplers below need it (cuda_functions.h:17,68: 2.0f * vec3(u..) - vec3(1..)).  The reference rounds once
+// (2u is exact); so does fma(k, 2^-23, 2^-23 - 1) with k = x >> 8, whose product and sum are exact before
+// the rounding: the same float from three instructions instead of six.
+PT_DI float u32_to_signed_unit(uint32_t x) { return __builtin_fmaf((float)(x >> 8), 1.0f / 8388608.0f, 1.0f / 8388608.0f - 1.0f); }
+
 // cuda_functions.h:14-20, one block per try
 PT_DI v3 random_in_unit_sphere(Rng &g)
 {
     v3 p;
     int tries = 0;
     do {
-        float u[4];
-        rng_block(g, u);
-        p = vsub(vscale(2.0f, V(u[0], u[1], u[2])), V(1.0f, 1.0f, 1.0f));
+        uint32_t o[4];
+        philox4x32_10(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
+        g.block++;
+        p = V(u32_to_signed_unit(o[0]), u32_to_signed_unit(o[1]), u32_to_signed_unit(o[2]));
     } while (vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES);
     return p;
 }
@@ -132,9 +143,10 @@ PT_DI v3 random_in_unit_disk(Rng &g)
     v3 p;
     int tries = 0;
     do {
-        float u[4];
-        rng_block(g, u);
-        p = vsub(vscale(2.0f, V(u[0], u[1], 0.0f)), V(1.0f, 1.0f, 0.0f));
+        uint32_t o[4];
+        philox4x32_10(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
+        g.block++;
+        p = V(u32_to_signed_unit(o[0]), u32_to_signed_unit(o[1]), 0.0f);
     } while (vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES);
     return p;
 }

@@ -1,17 +1,22 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
-__global__ void k(uint32_t *o, const uint32_t *x)
+__global__ void k(uint32_t *o, const uint32_t *x, uint32_t key)
 {
-    uint32_t a = x[threadIdx.x], b = x[threadIdx.x + 64], c = x[threadIdx.x + 128];
-    unsigned long long p;
-    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(a), "v"(b) : "vcc");
+    uint32_t a = x[threadIdx.x], b = x[threadIdx.x + 64];
     uint32_t r;
-    asm volatile("v_xor3_b32 %0, %1, %2, %3" : "=v"(r) : "v"((uint32_t)p), "v"((uint32_t)(p >> 32)), "v"(c));
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(key));
     o[threadIdx.x] = r;
 }
-__global__ void k2(uint32_t *o, const uint32_t *x)
+int main()
 {
-    uint32_t a = x[threadIdx.x];
-    unsigned long long p = (unsigned long long)a * 0xD2511F53u;
-    o[threadIdx.x] = (uint32_t)p ^ (uint32_t)(p >> 32);
+    uint32_t *d, h[128], out[64];
+    for (int i = 0; i < 128; ++i) h[i] = 0x9E3779B9u * (i + 1);
+    hipMalloc(&d, 4 * 256);
+    hipMemcpy(d + 64, h, 4 * 128, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, d + 64, 0xDEADBEEFu);
+    hipMemcpy(out, d, 4 * 64, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 64; ++i) bad += out[i] != (h[i] ^ h[i + 64] ^ 0xDEADBEEFu);
+    printf("bitop3 xor3 mismatches: %d\n", bad);
+    return bad != 0;
 }
