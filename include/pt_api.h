@@ -157,6 +157,20 @@ pt_status pt_film_finalize(const float *rgb_sum, int32_t width, int32_t height, 
 pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
                             uint32_t *order_out);
 
+/* How wide a cone the traversal gives its rays in this scene (host-side tests, no GPU needed).  The
+ * reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) accept hits up to
+ * about 2^-10 of the origin-to-object distance outside the exact surfaces; the tree culls against a
+ * cone of that slope (kappa_max), narrowed per ray (adaptive != 0) to the chord slope of the excess
+ * sqrt(r_min^2 + (kappa_max D)^2) - r_min over the ray origin's L1 reach D = |o - cluster_centre|_1 +
+ * cluster_half_extent_sum to the objects that rely on it, never below kappa_min. */
+typedef struct pt_ray_cone {
+    float kappa_max, kappa_min, r_min;
+    float cluster_centre[3];
+    float cluster_half_extent_sum;
+    uint32_t adaptive;
+} pt_ray_cone;
+pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *out);
+
 /* Library build id, e.g. "pathtracer_amd 0.1 gfx950". */
 const char *pt_version(void);
 

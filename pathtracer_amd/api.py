@@ -24,7 +24,7 @@ FLT_MAX = float(np.finfo(np.float32).max)
 EXPORTS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
-    "pt_bvh_build_host", "pt_version",
+    "pt_bvh_build_host", "pt_scene_ray_cone", "pt_version",
 ]
 
 
@@ -38,6 +38,11 @@ class PtCamera(C.Structure):
     _fields_ = [(n, C.c_float * 3) for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")] + [
         ("lens_radius", C.c_float)
     ]
+
+
+class PtRayCone(C.Structure):
+    _fields_ = [("kappa_max", C.c_float), ("kappa_min", C.c_float), ("r_min", C.c_float), ("cluster_centre", C.c_float * 3),
+                ("cluster_half_extent_sum", C.c_float), ("adaptive", C.c_uint32)]
 
 
 class PtSceneDesc(C.Structure):
@@ -121,6 +126,7 @@ def lib():
         L.pt_film_finalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pt_camera_look_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(PtCamera)]
         L.pt_bvh_build_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.pt_scene_ray_cone.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRayCone)]
         _lib = L
     return _lib
 
@@ -186,6 +192,17 @@ def bvh_build_host(desc):
     if st != PT_OK:
         raise PtError(st, "pt_bvh_build_host")
     return nodes, order, depth.value
+
+
+def scene_ray_cone(desc):
+    """pt_scene_ray_cone as a dict (host only)."""
+    out = PtRayCone()
+    st = lib().pt_scene_ray_cone(C.byref(desc.c), C.byref(out))
+    if st != PT_OK:
+        raise PtError(st, "pt_scene_ray_cone")
+    return {"kappa_max": out.kappa_max, "kappa_min": out.kappa_min, "r_min": out.r_min,
+            "cluster_centre": tuple(out.cluster_centre), "cluster_half_extent_sum": out.cluster_half_extent_sum,
+            "adaptive": bool(out.adaptive)}
 
 
 def film_finalize(rgb_sum, total_spp):

@@ -1293,6 +1293,23 @@ extern "C" pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_no
     return PT_OK;
 }
 
+extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *out)
+{
+    if (!out) return PT_ERR_INVALID;
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return PT_ERR_INVALID;
+    pt::BvhBuild b;
+    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    if (!e.empty()) return PT_ERR_INVALID;
+    out->kappa_max = b.cone.kappa_max;
+    out->kappa_min = b.cone.kappa_min;
+    out->r_min = b.cone.r_min;
+    for (int a = 0; a < 3; ++a) out->cluster_centre[a] = b.cone.qc[a];
+    out->cluster_half_extent_sum = b.cone.qh;
+    out->adaptive = b.cone.adaptive;
+    return PT_OK;
+}
+
 extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
 {
     if (!ctx) return PT_ERR_INVALID;

@@ -179,3 +179,70 @@ def test_random_spheres_scene_is_the_named_workload():
     assert len(a["prim_type"]) == 485 and (a["prim_type"] == api.SPHERE).all()
     kinds = a["mat_type"][a["prim_material"]]
     assert (kinds == api.LAMBERTIAN).sum() > 350 and (kinds == api.METAL).sum() > 40 and (kinds == api.DIELECTRIC).sum() > 10
+
+
+def test_ray_cone_parameters():
+    """How wide a cone the traversal gives its rays (pt_scene_ray_cone): per-ray for sphere / cylinder scenes,
+    rounding-level for rect-only scenes, fixed and slope-scaled for scenes with cones."""
+    k = 2.0 ** -10
+    c2 = api.scene_ray_cone(scenes.random_spheres_scene().desc())
+    assert c2["adaptive"] and c2["kappa_max"] == k and c2["kappa_min"] == 2.0 ** -20
+    assert abs(c2["r_min"] - 0.2) < 1e-6                      # the ground sphere (r = 1000) carries its own padding
+    assert c2["cluster_half_extent_sum"] < 40 and max(abs(v) for v in c2["cluster_centre"]) < 5
+    # a camera ray of that scene: origin (13, 2, 3), reach ~ 50 -> slope far below kappa_max
+    d1 = sum(abs(o - c) for o, c in zip((13.0, 2.0, 3.0), c2["cluster_centre"])) + c2["cluster_half_extent_sum"]
+    eta = k * d1
+    assert k * eta / (max(c2["r_min"], eta) + c2["r_min"]) < 0.2 * k
+
+    box = scenes.SceneBuilder()
+    mw = box.lambertian((0.7, 0.7, 0.7))
+    box.xz_rect(0, 5, 0, 5, 0, mw)
+    box.xy_rect(0, 5, 0, 5, 5, mw)
+    box.yz_rect(0, 5, 0, 5, 0, mw)
+    box.camera((2, 2, -8), (2, 2, 0), (0, 1, 0), 40.0, 1.0, 0.0, 8.0)
+    rects = api.scene_ray_cone(box.desc())
+    assert not rects["adaptive"] and rects["kappa_max"] == 2.0 ** -20
+    # the Cornell box's one cylinder is large against the room and carries its own padding: rounding-level cone
+    cornell = api.scene_ray_cone(scenes.cornell_scene().desc())
+    assert cornell["adaptive"] and cornell["r_min"] > 1e29
+
+    b = scenes.SceneBuilder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    b.sphere((0, 0, 0), 1.0, m)
+    b.cone((3, 0, 0), 0.5, 1.0, m)                            # radius / height = 2
+    b.camera((0, 0, 9), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 9.0)
+    cones = api.scene_ray_cone(b.desc())
+    assert not cones["adaptive"] and abs(cones["kappa_max"] - 2 * k) < 1e-9
+
+    tiny = scenes.SceneBuilder()
+    tiny.sphere((0, 0, 0), 0.0, tiny.lambertian((1, 1, 1)))   # a zero radius leaves no room to narrow the cone
+    tiny.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    z = api.scene_ray_cone(tiny.desc())
+    assert z["adaptive"] and z["r_min"] == 0.0
+
+
+def test_leaf_boxes_carry_the_objects_share_of_the_cone():
+    """An object's box is padded by kappa_max x its own extent (a cone that grows with the distance travelled
+    cannot see the part of the origin-to-centre distance that lies inside the object), or by its whole
+    worst-case excess when it is large enough to carry that itself."""
+    b = scenes.random_spheres_scene()
+    d = b.desc()
+    nodes, order, _ = api.bvh_build_host(d)
+    pp = b.arrays()["prim_param"]
+    k = 2.0 ** -10
+    found = 0
+    for nd in nodes:
+        for child in range(2):
+            ref = int(nd["c"][child])
+            if ref >= 0 or not np.isfinite(nd["lo"][:, child]).all():
+                continue
+            r = ~ref
+            first, count = r >> 3, (r & 7) + 1
+            for s in range(first, first + count):
+                c, rad = pp[order[s]][:3], abs(pp[order[s]][3])
+                pad_lo = (c - rad) - nd["lo"][:, child]
+                pad_hi = nd["hi"][:, child] - (c + rad)
+                need = k * rad if rad < 100 else 0.0
+                assert (pad_lo >= need).all() and (pad_hi >= need).all()
+                found += 1
+    assert found == len(pp)
