@@ -179,6 +179,32 @@ PT_DI bool hit_sphere(const PrimRec &q, const Ray &r, float t_min, float t_max, 
     return true;
 }
 
+// hit_sphere() in two halves, for the traversal: the discriminant (sphere.h:85-93; false when negative)
+// and the roots with their range tests (sphere.h:94-101).  Same operations in the same order.
+PT_DI bool sphere_discriminant(const PrimRec &q, const Ray &r, float &half_b, float &discriminant)
+{
+    v3 center = V(q.p[0], q.p[1], q.p[2]);
+    float radius = q.p[3];
+    v3 oc = vsub(r.o, center);
+    float a = vlen2(r.d);
+    half_b = vdot(oc, r.d);
+    float c = vlen2(oc) - radius * radius;
+    discriminant = half_b * half_b - a * c;
+    return !(discriminant < 0);
+}
+PT_DI bool sphere_roots(const Ray &r, float half_b, float discriminant, float t_min, float t_max, float &t_out)
+{
+    float a = vlen2(r.d);
+    float sqrtd = sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_out = root;
+    return true;
+}
+
 PT_DI float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // aarect.h:348-355 (AX=2: xy), :364-371 (AX=1: xz), :380-387 (AX=0: yz)

@@ -55,7 +55,7 @@ struct Counters { // device memory, zeroed per call
     // Diagnostics of a -DPT_SECTION_CLOCKS build only (k_paths): clock ticks per code section summed
     // over waves, and active-lane / issued-lane slot counts of the three divergent loops.
     unsigned long long sect[8];
-    unsigned long long lanes[4], slots[4];
+    unsigned long long lanes[6], slots[6];
 };
 
 #ifdef PT_SECTION_CLOCKS
@@ -64,7 +64,7 @@ constexpr bool kProf = true;
 constexpr bool kProf = false;
 #endif
 struct ProfLanes { // per-lane tallies; slots are counted by the first active lane of each issue
-    uint32_t lanes[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0};
+    uint32_t lanes[6] = {0, 0, 0, 0, 0, 0}, slots[6] = {0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void tick(int k)
     {
         if (kProf) {
@@ -398,6 +398,29 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         {
             uint32_t ref = (uint32_t)~cur;
             uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+            // Spheres are taken in two steps.  Their discriminant test is cheap and rejects most of a leaf's
+            // spheres; the roots (a correctly rounded sqrt and one or two divides) are the expensive part.
+            // Computing them where the discriminant is found would run that part once per leaf position at
+            // which ANY lane of the wave has a candidate.  Instead a lane holds its candidate back until it
+            // finds another one or the leaf ends, so that most lanes compute their roots together after the
+            // loop.  The nearest hit does not depend on the order in which spheres, rects and cylinders are
+            // tried (equal t goes to the later list entry either way).
+            bool held = false;
+            float held_hb = 0.0f, held_disc = 0.0f;
+            uint32_t held_slot = 0, held_id = 0;
+            auto take = [&](bool h, float t, uint32_t slot, uint32_t id) {
+                if (h && (t < best_t || best_slot == PT_NO_PRIM || id > best_id)) {
+                    best_t = t;
+                    best_slot = slot;
+                    best_id = id;
+                }
+            };
+            auto release = [&]() {
+                float t = 0.0f;
+                const bool h = sphere_roots(r, held_hb, held_disc, t_min, best_t, t);
+                if (kProf && prof) prof->tick(4);
+                take(h, t, held_slot, held_id);
+            };
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t slot = first + k;
                 float4 w0, w1;
@@ -409,15 +432,21 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 if (COUNT) n_prim += 1;
                 if (kProf && prof) prof->tick(1);
                 float t = 0.0f;
-                bool h;
+                bool h = false;
                 switch (q.meta & 7u) {
-                case PT_SPHERE: h = hit_sphere(q, r, t_min, best_t, t); break;
+                case PT_SPHERE: {
+                    float hb, disc;
+                    if (sphere_discriminant(q, r, hb, disc)) {
+                        if (held) release();
+                        held = true; held_hb = hb; held_disc = disc; held_slot = slot; held_id = q.id;
+                    }
+                    break;
+                }
                 case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best_t, t); break;
                 case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best_t, t); break;
                 case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, best_t, t); break;
                 case PT_CONE: {
                     ConeRoots cr;
-                    h = false;
                     if (CONES && cone_roots(q, r, cr)) {
                         if (!(cr.a < 0.0f)) {
                             h = hit_cone_ordered(cr, t_min, best_t, t);
@@ -443,12 +472,9 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 }
                 default: h = hit_cylinder(q, r, t_min, best_t, t); break;
                 }
-                if (h && (t < best_t || best_slot == PT_NO_PRIM || q.id > best_id)) {
-                    best_t = t;
-                    best_slot = slot;
-                    best_id = q.id;
-                }
+                take(h, t, slot, q.id);
             }
+            if (held) release();
         }
         if (sp == 0) break;
         cur = (int32_t)stack[(--sp) * STRIDE];
@@ -1060,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         mark(5);
     }
     if (kProf) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 6; ++k) {
             const unsigned long long a = wave_sum_u32(prof.lanes[k]), b2 = wave_sum_u32(prof.slots[k]);
             if (lane == 0) { atomicAdd(&cnt->lanes[k], a); atomicAdd(&cnt->slots[k], b2); }
         }
@@ -1603,8 +1629,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
             unsigned long long tot = 0;
             for (int k = 0; k < 6; ++k) tot += h.sect[k];
             for (int k = 0; k < 6; ++k) fprintf(stderr, "[prof] %-20s %5.1f %% of wave time\n", names[k], 100.0 * (double)h.sect[k] / (double)std::max(tot, 1ull));
-            static const char *ln[4] = {"node visits", "object tests", "sphere-sample tries", "shade calls"};
-            for (int k = 0; k < 4; ++k)
+            static const char *ln[6] = {"node visits", "object tests", "sphere-sample tries", "shade calls", "sphere roots", "-"};
+            for (int k = 0; k < 5; ++k)
                 fprintf(stderr, "[prof] %-20s lanes %llu slots %llu utilisation %.1f %%\n", ln[k], h.lanes[k], h.slots[k], 100.0 * (double)h.lanes[k] / (double)std::max(h.slots[k], 1ull));
         }
         float ms = 0.0f;
