@@ -75,7 +75,7 @@ class PtStats(C.Structure):
 HIT_DTYPE = np.dtype(
     [("t", "<f4"), ("prim", "<u4"), ("n", "<f4", (3,)), ("front", "<u4"), ("p", "<f4", (3,)), ("flags", "<u4")]
 )
-NODE_DTYPE = np.dtype([("lo", "<f4", (3, 2)), ("hi", "<f4", (3, 2)), ("c", "<i4", (2,)), ("pad", "<u4", (2,))])  # [axis][child]
+NODE_DTYPE = np.dtype([("b", "<f4", (3, 4)), ("c", "<i4", (2,)), ("pad", "<u4", (2,))])  # b[axis] = (lo child 0, lo child 1, hi child 0, hi child 1)
 
 _lib = None
 

@@ -146,8 +146,8 @@ struct Builder {
         int32_t c1 = nr > leaf_max ? build_inner(first + nl, nr, depth + 1) : leaf_ref(first + nl, nr);
         HostNode &n = nodes[me];
         for (int a = 0; a < 3; ++a) {
-            n.lo[a][0] = bl.lo[a]; n.hi[a][0] = bl.hi[a];
-            n.lo[a][1] = br.lo[a]; n.hi[a][1] = br.hi[a];
+            n.b[a][0] = bl.lo[a]; n.b[a][2] = bl.hi[a];
+            n.b[a][1] = br.lo[a]; n.b[a][3] = br.hi[a];
         }
         n.c[0] = c0;
         n.c[1] = c1;
@@ -285,8 +285,8 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
         HostNode n{};
         Box bl = b.range_box(0, d.n_prims);
         for (int a = 0; a < 3; ++a) {
-            n.lo[a][0] = bl.lo[a]; n.hi[a][0] = bl.hi[a];
-            n.lo[a][1] = kInf; n.hi[a][1] = kInf; // a point at infinity: no ray reaches it
+            n.b[a][0] = bl.lo[a]; n.b[a][2] = bl.hi[a];
+            n.b[a][1] = kInf; n.b[a][3] = kInf; // a point at infinity: no ray reaches it
         }
         n.c[0] = Builder::leaf_ref(0, d.n_prims);
         n.c[1] = Builder::leaf_ref(0, 1);

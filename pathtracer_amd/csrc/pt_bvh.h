@@ -8,9 +8,8 @@
 
 namespace pt {
 
-struct HostNode { // mirrors BvhNode (pt_device.h), 64 B: child boxes interleaved per axis
-    float lo[3][2];
-    float hi[3][2];
+struct HostNode { // mirrors BvhNode (pt_device.h), 64 B: per axis (lo child 0, lo child 1, hi child 0, hi child 1)
+    float b[3][4];
     int32_t c[2];
     uint32_t pad[2];
 };

@@ -29,13 +29,13 @@ struct __attribute__((aligned(16))) PrimRec {
 };
 static_assert(sizeof(PrimRec) == 32, "PrimRec must be 32 bytes");
 
-// One inner node, 64 B: the boxes of both children, interleaved per axis so that one packed
-// instruction handles both (lo[a][k] = lower bound of child k on axis a), and their references.
+// One inner node, 64 B: the boxes of both children as one quad per axis, b[a] = (lo of child 0, lo of
+// child 1, hi of child 0, hi of child 1) on axis a, and their references.  The half of a quad that holds
+// the planes a ray meets first is chosen by the sign of the ray's direction on that axis, i.e. by address.
 //   ref >= 0: inner node index.  ref < 0: leaf, ~ref = (first_prim << 3) | (count - 1).
 //   An absent child has the degenerate box lo = hi = +inf (no ray reaches it) and ref = leaf of count 1 at 0.
 struct __attribute__((aligned(16))) BvhNode {
-    float lo[3][2];
-    float hi[3][2];
+    float b[3][4];
     int32_t c[2];
     uint32_t pad[2];
 };

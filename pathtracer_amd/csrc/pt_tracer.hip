@@ -133,15 +133,19 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
 // Per axis x with w = kappa |d| / |d_x|, the condition  lo - kappa|d|t <= o + t d_x <= hi + kappa|d|t
 // is  t >= near / (1 + w)  and, when w < 1,  t <= far / (1 - w)  (no upper bound otherwise), with
 // near/far the plane distances (bound - o) / d_x.  Both are still one FMA per plane: the factors are
-// folded into per-ray constants  t = bound * A + C,  one pair for the plane that is the near one
-// for this ray's direction sign and one for the far one.
+// folded into per-ray constants  t = bound * A + C,  one pair for the planes the ray meets first on
+// that axis and one for the planes it meets last.  Which planes those are (lo or hi) follows from the
+// sign of the direction, and a node stores each axis as (lo, lo, hi, hi): the near pair is read from
+// byte offset 0 or 8 of the quad, the far pair from the other half, so no per-axis min/max is needed
+// (on gfx950 a min/max issues at half the rate of an FMA).
 struct BoxRay {
-    float alx, aly, alz, clx, cly, clz; // constants applied to a box's lo planes
-    float ahx, ahy, ahz, chx, chy, chz; // constants applied to its hi planes
+    float anx, any, anz, cnx, cny, cnz; // constants applied to the near planes
+    float afx, afy, afz, cfx, cfy, cfz; // constants applied to the far planes
+    uint32_t sx, sy, sz;                // byte offset of the near pair within an axis quad: 0 (lo planes near) or 8
     float eps;                          // absolute error bound of a plane distance (rounding of o * inv)
 };
 
-PT_DI void box_ray_axis(float o, float d, float kd, float &a_lo, float &c_lo, float &a_hi, float &c_hi, float &cmax)
+PT_DI void box_ray_axis(float o, float d, float kd, float &a_n, float &c_n, float &a_f, float &c_f, uint32_t &near_off, float &cmax)
 {
     // A component of exactly (or nearly) zero would make the reciprocal infinite; the box test sees such
     // a ray as very slightly tilted instead (2^-60), which keeps every distance finite.  Only the pruning
@@ -152,8 +156,8 @@ PT_DI void box_ray_axis(float o, float d, float kd, float &a_lo, float &c_lo, fl
     const float w = kd * fabsf(inv);               // kappa |d| / |d_x|
     const float g = __builtin_amdgcn_rcpf(1.0f + w) * 0.99999809f; // 1/(1+w), rounded down by 2^-19
     const float no = -(o * inv);
-    const float a_n = inv * g, c_n = no * g;       // near plane
-    float a_f, c_f;
+    a_n = inv * g;                                 // near plane
+    c_n = no * g;
     if (w < 0.99f) {
         const float f = __builtin_amdgcn_rcpf(1.0f - w) * 1.00000191f; // 1/(1-w), rounded up by 2^-19
         a_f = inv * f;
@@ -164,9 +168,7 @@ PT_DI void box_ray_axis(float o, float d, float kd, float &a_lo, float &c_lo, fl
         c_f = 3.0e38f;
     }
     cmax = fmaxf(cmax, fabsf(c_n));
-    const bool pos = dd > 0.0f; // lo is the near plane
-    a_lo = pos ? a_n : a_f; c_lo = pos ? c_n : c_f;
-    a_hi = pos ? a_f : a_n; c_hi = pos ? c_f : c_n;
+    near_off = dd > 0.0f ? 0u : 8u; // d > 0: the lo planes are met first
 }
 
 // Slope of the cone for a ray from origin o (pt::ConeParams): the chord slope f(Dm) / Dm of the excess
@@ -189,9 +191,9 @@ PT_DI BoxRay make_box_ray(const Ray &r, float kappa)
     // |d| from the hardware sqrt, rounded up: kd only has to be an upper bound of kappa |d|
     const float kd = kappa * __builtin_amdgcn_sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z) * 1.000001f;
     float cmax = 0.0f;
-    box_ray_axis(r.o.x, r.d.x, kd, b.alx, b.clx, b.ahx, b.chx, cmax);
-    box_ray_axis(r.o.y, r.d.y, kd, b.aly, b.cly, b.ahy, b.chy, cmax);
-    box_ray_axis(r.o.z, r.d.z, kd, b.alz, b.clz, b.ahz, b.chz, cmax);
+    box_ray_axis(r.o.x, r.d.x, kd, b.anx, b.cnx, b.afx, b.cfx, b.sx, cmax);
+    box_ray_axis(r.o.y, r.d.y, kd, b.any, b.cny, b.afy, b.cfy, b.sy, cmax);
+    box_ray_axis(r.o.z, r.d.z, kd, b.anz, b.cnz, b.afz, b.cfz, b.sz, cmax);
     b.eps = cmax * (1.0f / 4194304.0f); // 2^-22 * max|C|: twice the rounding bound of C and of bound * A near the origin
     return b;
 }
@@ -201,20 +203,22 @@ PT_DI BoxRay make_box_ray(const Ray &r, float kappa)
 // a distance by at most eps absolutely and 2^-22 relatively (reciprocal 2^-23, constant 2^-24, FMA
 // 2^-24); the relative part is inside the 2^-19 by which the cone factors were rounded outwards.  A
 // box the exact test accepts is therefore never rejected.
-PT_DI void box_test2(const float4 &q0, const float4 &q1, const float4 &q2, const BoxRay &b, float t_min, float t_best,
-                     bool &h0, bool &h1, float &tn0, float &tn1)
+PT_DI void box_test2(const float2 &nx, const float2 &ny, const float2 &nz, const float2 &fx, const float2 &fy, const float2 &fz,
+                     const BoxRay &b, float t_min, float t_best, bool &h0, bool &h1, float &tn0, float &tn1)
 {
-    // q0 = (lo0.x lo1.x lo0.y lo1.y)  q1 = (lo0.z lo1.z hi0.x hi1.x)  q2 = (hi0.y hi1.y hi0.z hi1.z)
-    const float a0x = __builtin_fmaf(q0.x, b.alx, b.clx), a1x = __builtin_fmaf(q0.y, b.alx, b.clx);
-    const float a0y = __builtin_fmaf(q0.z, b.aly, b.cly), a1y = __builtin_fmaf(q0.w, b.aly, b.cly);
-    const float a0z = __builtin_fmaf(q1.x, b.alz, b.clz), a1z = __builtin_fmaf(q1.y, b.alz, b.clz);
-    const float b0x = __builtin_fmaf(q1.z, b.ahx, b.chx), b1x = __builtin_fmaf(q1.w, b.ahx, b.chx);
-    const float b0y = __builtin_fmaf(q2.x, b.ahy, b.chy), b1y = __builtin_fmaf(q2.y, b.ahy, b.chy);
-    const float b0z = __builtin_fmaf(q2.z, b.ahz, b.chz), b1z = __builtin_fmaf(q2.w, b.ahz, b.chz);
-    tn0 = fmaxf(fmaxf(fminf(a0x, b0x), fminf(a0y, b0y)), fmaxf(fminf(a0z, b0z), t_min));
-    tn1 = fmaxf(fmaxf(fminf(a1x, b1x), fminf(a1y, b1y)), fmaxf(fminf(a1z, b1z), t_min));
-    const float tf0 = fminf(fminf(fmaxf(a0x, b0x), fmaxf(a0y, b0y)), fminf(fmaxf(a0z, b0z), t_best));
-    const float tf1 = fminf(fminf(fmaxf(a1x, b1x), fmaxf(a1y, b1y)), fminf(fmaxf(a1z, b1z), t_best));
+    // n* = near planes of (child 0, child 1) per axis, f* = far planes
+    const float n0x = __builtin_fmaf(nx.x, b.anx, b.cnx), n1x = __builtin_fmaf(nx.y, b.anx, b.cnx);
+    const float n0y = __builtin_fmaf(ny.x, b.any, b.cny), n1y = __builtin_fmaf(ny.y, b.any, b.cny);
+    const float n0z = __builtin_fmaf(nz.x, b.anz, b.cnz), n1z = __builtin_fmaf(nz.y, b.anz, b.cnz);
+    const float f0x = __builtin_fmaf(fx.x, b.afx, b.cfx), f1x = __builtin_fmaf(fx.y, b.afx, b.cfx);
+    const float f0y = __builtin_fmaf(fy.x, b.afy, b.cfy), f1y = __builtin_fmaf(fy.y, b.afy, b.cfy);
+    const float f0z = __builtin_fmaf(fz.x, b.afz, b.cfz), f1z = __builtin_fmaf(fz.y, b.afz, b.cfz);
+    // An axis without a far bound gives 3e38, or NaN for the infinite planes of an absent child: fminf /
+    // fmaxf drop a NaN operand, and such a child is rejected by its infinite near or far distance.
+    tn0 = fmaxf(fmaxf(n0x, n0y), fmaxf(n0z, t_min));
+    tn1 = fmaxf(fmaxf(n1x, n1y), fmaxf(n1z, t_min));
+    const float tf0 = fminf(fminf(f0x, f0y), fminf(f0z, t_best));
+    const float tf1 = fminf(fminf(f1x, f1y), fminf(f1z, t_best));
     h0 = tn0 <= tf0 + b.eps;
     h1 = tn1 <= tf1 + b.eps;
 }
@@ -237,10 +241,17 @@ struct GlobalSrc {
     const BvhNode *nodes;
     const PrimRec *prims;
     pt::ConeParams cone;
-    __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
+    // near / far plane pairs of node i for this ray, and the children's references
+    __device__ __forceinline__ void planes(int32_t i, const BoxRay &br, float2 &nx, float2 &ny, float2 &nz, float2 &fx, float2 &fy,
+                                           float2 &fz, int32_t &c0, int32_t &c1) const
     {
         const float4 *np = reinterpret_cast<const float4 *>(nodes + i);
-        a = np[0]; b = np[1]; c = np[2]; d = np[3];
+        const float4 a = np[0], b = np[1], c = np[2], d = np[3];
+        nx = br.sx ? make_float2(a.z, a.w) : make_float2(a.x, a.y); fx = br.sx ? make_float2(a.x, a.y) : make_float2(a.z, a.w);
+        ny = br.sy ? make_float2(b.z, b.w) : make_float2(b.x, b.y); fy = br.sy ? make_float2(b.x, b.y) : make_float2(b.z, b.w);
+        nz = br.sz ? make_float2(c.z, c.w) : make_float2(c.x, c.y); fz = br.sz ? make_float2(c.x, c.y) : make_float2(c.z, c.w);
+        c0 = __float_as_int(d.x);
+        c1 = __float_as_int(d.y);
     }
     __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
     {
@@ -253,9 +264,22 @@ struct LdsSrc {
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
     pt::ConeParams cone;
-    __device__ __forceinline__ void node(int32_t i, float4 &a, float4 &b, float4 &c, float4 &d) const
+    __device__ __forceinline__ void planes(int32_t i, const BoxRay &br, float2 &nx, float2 &ny, float2 &nz, float2 &fx, float2 &fy,
+                                           float2 &fz, int32_t &c0, int32_t &c1) const
     {
-        a = nodes[i]; b = nodes[n_nodes + i]; c = nodes[2 * n_nodes + i]; d = nodes[3 * n_nodes + i];
+        // plane a holds the quad of axis a of every node; the near pair sits at byte 0 or 8 of the quad
+        const char *base = reinterpret_cast<const char *>(nodes + i);
+        const uint32_t stride = n_nodes * 16u;
+        const char *px = base + br.sx, *py = base + stride + br.sy, *pz = base + 2u * stride + br.sz;
+        nx = *reinterpret_cast<const float2 *>(px);
+        ny = *reinterpret_cast<const float2 *>(py);
+        nz = *reinterpret_cast<const float2 *>(pz);
+        fx = *reinterpret_cast<const float2 *>(base + (br.sx ^ 8u));
+        fy = *reinterpret_cast<const float2 *>(base + stride + (br.sy ^ 8u));
+        fz = *reinterpret_cast<const float2 *>(base + 2u * stride + (br.sz ^ 8u));
+        const int2 c = *reinterpret_cast<const int2 *>(base + 3u * stride);
+        c0 = c.x;
+        c1 = c.y;
     }
     __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
     {
@@ -282,12 +306,12 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
     int32_t cur = 0;
     for (;;) {
         if (cur >= 0) {
-            float4 a, b, c, d;
-            src.node(cur, a, b, c, d);
-            const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+            float2 nx, ny, nz, fx, fy, fz;
+            int32_t c0, c1;
+            src.planes(cur, br, nx, ny, nz, fx, fy, fz, c0, c1);
             float tn0, tn1;
             bool h0, h1;
-            box_test2(a, b, c, br, t_min, t_max, h0, h1, tn0, tn1);
+            box_test2(nx, ny, nz, fx, fy, fz, br, t_min, t_max, h0, h1, tn0, tn1);
             if (h0 && h1) {
                 if (sp < stack_cap) stack[(sp++) * STRIDE] = (uint32_t)c1;
                 else overflow = true;
@@ -370,12 +394,12 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         // Descend until this lane holds a leaf (or has nothing left); lanes that found theirs wait here, so
         // that the expensive object tests below run with as many lanes of the wave as possible.
         while (cur >= 0) {
-            float4 a, b, c, d;
-            src.node(cur, a, b, c, d);
-            const int32_t c0 = __float_as_int(d.x), c1 = __float_as_int(d.y);
+            float2 nx, ny, nz, fx, fy, fz;
+            int32_t c0, c1;
+            src.planes(cur, br, nx, ny, nz, fx, fy, fz, c0, c1);
             float tn0, tn1;
             bool h0, h1;
-            box_test2(a, b, c, br, t_min, best_t, h0, h1, tn0, tn1);
+            box_test2(nx, ny, nz, fx, fy, fz, br, t_min, best_t, h0, h1, tn0, tn1);
             if (COUNT) n_box += 2;
             if (kProf && prof) prof->tick(0);
             if (h0 && h1) {

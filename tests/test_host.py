@@ -82,7 +82,7 @@ def _check_tree(desc, nodes, order, leaf_max=4):
                 assert (plo >= lo - 1e-6).all() and (phi <= hi + 1e-6).all()  # the (padded) node box encloses the object
             return depth
         nd = nodes[ref]
-        kids = [(nd["lo"][:, k], nd["hi"][:, k]) for k in range(2)]
+        kids = [(nd["b"][:, k], nd["b"][:, 2 + k]) for k in range(2)]
         for clo, chi in kids:
             if np.isfinite(clo).all():
                 assert (clo >= lo - 1e-6).all() and (chi <= hi + 1e-6).all()  # children inside the parent
@@ -120,7 +120,7 @@ def test_bvh_degenerate_inputs():
     one.sphere((0, 0, 0), 1, one.lambertian((1, 1, 1)))
     one.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
     nodes, order, max_depth = api.bvh_build_host(one.desc())
-    assert len(nodes) == 1 and max_depth == 1 and list(order) == [0] and not np.isfinite(nodes[0]["lo"][:, 1]).any()
+    assert len(nodes) == 1 and max_depth == 1 and list(order) == [0] and not np.isfinite(nodes[0]["b"][:, 1]).any()
 
 
 def test_bad_scenes_are_rejected_not_crashed():
@@ -234,14 +234,14 @@ def test_leaf_boxes_carry_the_objects_share_of_the_cone():
     for nd in nodes:
         for child in range(2):
             ref = int(nd["c"][child])
-            if ref >= 0 or not np.isfinite(nd["lo"][:, child]).all():
+            if ref >= 0 or not np.isfinite(nd["b"][:, child]).all():
                 continue
             r = ~ref
             first, count = r >> 3, (r & 7) + 1
             for s in range(first, first + count):
                 c, rad = pp[order[s]][:3], abs(pp[order[s]][3])
-                pad_lo = (c - rad) - nd["lo"][:, child]
-                pad_hi = nd["hi"][:, child] - (c + rad)
+                pad_lo = (c - rad) - nd["b"][:, child]
+                pad_hi = nd["b"][:, 2 + child] - (c + rad)
                 need = k * rad if rad < 100 else 0.0
                 assert (pad_lo >= need).all() and (pad_hi >= need).all()
                 found += 1
