@@ -215,10 +215,17 @@ PT_DI void box_test2(const float2 &nx, const float2 &ny, const float2 &nz, const
     const float f0z = __builtin_fmaf(fz.x, b.afz, b.cfz), f1z = __builtin_fmaf(fz.y, b.afz, b.cfz);
     // An axis without a far bound gives 3e38, or NaN for the infinite planes of an absent child: fminf /
     // fmaxf drop a NaN operand, and such a child is rejected by its infinite near or far distance.
-    tn0 = fmaxf(fmaxf(n0x, n0y), fmaxf(n0z, t_min));
-    tn1 = fmaxf(fmaxf(n1x, n1y), fmaxf(n1z, t_min));
-    const float tf0 = fminf(fminf(f0x, f0y), fminf(f0z, t_best));
-    const float tf1 = fminf(fminf(f1x, f1y), fminf(f1z, t_best));
+    // (written as instructions: through fminf / fmaxf the compiler first re-canonicalises t_best with an
+    // extra v_max per visit, which IEEE minNum asks for and these finite-or-quiet-NaN values do not need)
+    float m0, m1, tf0, tf1;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(n0z), "v"(t_min));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(n1z), "v"(t_min));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn0) : "v"(n0x), "v"(n0y), "v"(m0));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn1) : "v"(n1x), "v"(n1y), "v"(m1));
+    asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(f0z), "v"(t_best));
+    asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(f1z), "v"(t_best));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf0) : "v"(f0x), "v"(f0y), "v"(m0));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf1) : "v"(f1x), "v"(f1y), "v"(m1));
     h0 = tn0 <= tf0 + b.eps;
     h1 = tn1 <= tf1 + b.eps;
 }
@@ -457,15 +464,16 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 if (kProf && prof) prof->tick(1);
                 float t = 0.0f;
                 bool h = false;
-                switch (q.meta & 7u) {
-                case PT_SPHERE: {
+                const uint32_t type = q.meta & 7u;
+                if (type == PT_SPHERE) { // the common object first: one compare instead of the switch's search
                     float hb, disc;
                     if (sphere_discriminant(q, r, hb, disc)) {
                         if (held) release();
                         held = true; held_hb = hb; held_disc = disc; held_slot = slot; held_id = q.id;
                     }
-                    break;
+                    continue;
                 }
+                switch (type) {
                 case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best_t, t); break;
                 case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best_t, t); break;
                 case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, best_t, t); break;
