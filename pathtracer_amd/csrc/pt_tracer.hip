@@ -244,6 +244,17 @@ PT_DI void box_test2(const float2 &nx, const float2 &ny, const float2 &nz, const
 // in L2 / Infinity Cache).  LdsSrc: a copy in the workgroup's LDS for scenes that fit, stored as float4
 // PLANES (quarter j of every node in plane j) so that the 64 lanes of one ds_read_b128 spread over all
 // sixteen 16-byte bank slots instead of the four a 64-byte-strided record array would use.
+// near / far plane pairs of a node record (one quad per axis, then the children's references) for a ray
+PT_DI void planes_of_record(const float4 &a, const float4 &b, const float4 &c, const float4 &d, const BoxRay &br, float2 &nx, float2 &ny,
+                            float2 &nz, float2 &fx, float2 &fy, float2 &fz, int32_t &c0, int32_t &c1)
+{
+    nx = br.sx ? make_float2(a.z, a.w) : make_float2(a.x, a.y); fx = br.sx ? make_float2(a.x, a.y) : make_float2(a.z, a.w);
+    ny = br.sy ? make_float2(b.z, b.w) : make_float2(b.x, b.y); fy = br.sy ? make_float2(b.x, b.y) : make_float2(b.z, b.w);
+    nz = br.sz ? make_float2(c.z, c.w) : make_float2(c.x, c.y); fz = br.sz ? make_float2(c.x, c.y) : make_float2(c.z, c.w);
+    c0 = __float_as_int(d.x);
+    c1 = __float_as_int(d.y);
+}
+
 struct GlobalSrc {
     const BvhNode *nodes;
     const PrimRec *prims;
@@ -253,12 +264,7 @@ struct GlobalSrc {
                                            float2 &fz, int32_t &c0, int32_t &c1) const
     {
         const float4 *np = reinterpret_cast<const float4 *>(nodes + i);
-        const float4 a = np[0], b = np[1], c = np[2], d = np[3];
-        nx = br.sx ? make_float2(a.z, a.w) : make_float2(a.x, a.y); fx = br.sx ? make_float2(a.x, a.y) : make_float2(a.z, a.w);
-        ny = br.sy ? make_float2(b.z, b.w) : make_float2(b.x, b.y); fy = br.sy ? make_float2(b.x, b.y) : make_float2(b.z, b.w);
-        nz = br.sz ? make_float2(c.z, c.w) : make_float2(c.x, c.y); fz = br.sz ? make_float2(c.x, c.y) : make_float2(c.z, c.w);
-        c0 = __float_as_int(d.x);
-        c1 = __float_as_int(d.y);
+        planes_of_record(np[0], np[1], np[2], np[3], br, nx, ny, nz, fx, fy, fz, c0, c1);
     }
     __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
     {
@@ -375,6 +381,99 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
         }
     }
     return best;
+}
+
+// The running answer of one ray's scan: the nearest accepted hit so far and, for scenes with cones,
+// the parked candidate (see above).  k_paths_stream keeps one per lane across its steps; bvh_nearest
+// below keeps the same state in locals (measured 6 % faster on the small scenes than going through this).
+struct Nearest {
+    float best_t;
+    uint32_t best_slot, best_id;
+    uint32_t n_pend, pend_slot, pend_id;
+    float pend_r2, pend_r1;
+    __device__ __forceinline__ void reset(float t_max)
+    {
+        best_t = t_max;
+        best_slot = PT_NO_PRIM;
+        best_id = 0;
+        n_pend = 0; pend_slot = 0; pend_id = 0;
+        pend_r2 = 0.0f; pend_r1 = 0.0f;
+    }
+    // equal t: the later list entry wins, as in the scan (hittable_list.h:93-95)
+    __device__ __forceinline__ void take(bool h, float t, uint32_t slot, uint32_t id)
+    {
+        if (h && (t < best_t || best_slot == PT_NO_PRIM || id > best_id)) {
+            best_t = t;
+            best_slot = slot;
+            best_id = id;
+        }
+    }
+};
+
+#define PT_TRAVERSAL_DONE INT32_MIN // not a leaf reference: those are > INT32_MIN for fewer than 2^28 objects
+
+// One object under the scan's rules, against the running nearest hit.  A cone whose nearer root may or
+// may not be reachable (see above) is parked in `nh` instead of decided.
+template <bool CONES>
+PT_DI void object_test(const PrimRec &q, uint32_t slot, const Ray &r, float t_min, float t_max, Nearest &nh)
+{
+    float t = 0.0f;
+    bool h = false;
+    switch (q.meta & 7u) {
+    case PT_SPHERE: h = hit_sphere(q, r, t_min, nh.best_t, t); break;
+    case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, nh.best_t, t); break;
+    case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, nh.best_t, t); break;
+    case PT_YZ_RECT: h = hit_rect<0, 1, 2>(q, r, t_min, nh.best_t, t); break;
+    case PT_CONE: {
+        ConeRoots cr;
+        if (CONES && cone_roots(q, r, cr)) {
+            if (!(cr.a < 0.0f)) {
+                h = hit_cone_ordered(cr, t_min, nh.best_t, t);
+            } else {
+                // larger root r1 first: an order-independent candidate
+                if (!(cr.r1 < t_min || nh.best_t < cr.r1) && cone_clip_ok(cr, cr.r1)) {
+                    h = true;
+                    t = cr.r1;
+                }
+                // nearer root r2: only reachable in the scan when its running t_max < r1
+                if (!(cr.r2 < t_min || nh.best_t < cr.r2) && !(cr.r1 < t_min) && cone_clip_ok(cr, cr.r2)) {
+                    if (t_max < cr.r1) { // no running t_max can reach r1: always the r2 branch
+                        h = true;
+                        t = cr.r2;
+                    } else {
+                        if (nh.n_pend == 0) { nh.pend_slot = slot; nh.pend_id = q.id; nh.pend_r2 = cr.r2; nh.pend_r1 = cr.r1; }
+                        nh.n_pend++;
+                    }
+                }
+            }
+        }
+        break;
+    }
+    default: h = hit_cylinder(q, r, t_min, nh.best_t, t); break;
+    }
+    nh.take(h, t, slot, q.id);
+}
+
+// After the traversal: decides the parked cone candidate where the traversal's knowledge suffices,
+// otherwise asks for the exact replay.
+template <bool CONES>
+PT_DI void settle_parked(Nearest &nh, bool &need_exact)
+{
+    if (!CONES) return;
+    if (nh.n_pend > 1) {
+        need_exact = true;
+    } else if (nh.n_pend == 1 && !(nh.best_t < nh.pend_r2)) {
+        // The parked cone is taken by the scan iff some EARLIER entry was accepted with t < pend_r1.
+        if (nh.best_slot != PT_NO_PRIM && nh.best_t < nh.pend_r1) {
+            if (nh.best_id < nh.pend_id) { // the nearest other hit is earlier in the list: it is such an entry
+                nh.best_t = nh.pend_r2;
+                nh.best_slot = nh.pend_slot;
+            } else {
+                need_exact = true; // nearest other hit is later in the list: earlier ones unknown
+            }
+        }
+        // else: nothing at all was hit nearer than pend_r1, so the scan took the larger root: not a hit here
+    }
 }
 
 // CONES = false compiles the cone case (and with it everything list-order dependent) out: the host
@@ -1137,6 +1236,218 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_paths_stream: the slice pipeline for scenes traversed from HBM, where every traversal step waits on
+// memory and rays differ widely in cost (1..5000 node visits on the 1M-sphere scene).  In k_paths a wave
+// traces 64 rays and waits for the slowest of them, and a workgroup waits at the end of every bounce for
+// its slowest ray: there 13 % of the lanes of a node visit are active, 60 % of the waves' time is spent at
+// that barrier, and a slice's critical path is the SUM over its bounces of the longest ray.  Here a lane
+// keeps a path from its camera ray to its end, and nothing is synchronised before the slice is finished:
+//  * a traversal step is the same for every lane whatever it holds: fetch the 64 bytes it needs next --
+//    an inner node, or the next two objects of its leaf -- then act on them; one memory round trip
+//    serves all lanes;
+//  * lanes whose traversal has finished wait until `serve_min` of them have (or nothing else is left to
+//    do); then they are shaded together -- the path scatters and the lane starts the next traversal, or
+//    the path ends and the lane takes the slice's next path (camera ray made on the spot).
+// There are no ray queues.  Same paths, same arithmetic, same film order: images are bit-identical to
+// k_paths.  (The vector ALUs are mostly idle on these scenes, so the lower lane utilisation of shading
+// in small groups costs nothing that matters.)
+// ---------------------------------------------------------------------------------------------
+#ifndef PT_STREAM_WAVES
+#define PT_STREAM_WAVES 5
+#endif
+template <bool COUNT, int BLOCK, bool CONES>
+__global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt,
+                                                                           uint32_t serve_min /* lanes waiting for shading or a new path before they are served */)
+{
+    extern __shared__ float4 s_mem[];
+    __shared__ uint32_t s_slice, s_next;
+    uint32_t *const stack = reinterpret_cast<uint32_t *>(s_mem) + threadIdx.x;
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.cone};
+    float *const rad = sl.rad + (size_t)blockIdx.x * 3 * sl.cap;
+    const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long rays = 0;
+    uint32_t nb = 0, np = 0, nf = 0, nr = 0;
+
+    for (;;) {
+        __syncthreads(); // previous slice's film pass is done with rad
+        if (threadIdx.x == 0) { s_slice = atomicAdd(sl.ticket, 1u); s_next = 0; }
+        __syncthreads();
+        const uint32_t slice = s_slice;
+        if (slice >= sl.n_slices) break;
+        const uint32_t pix0 = slice * sl.pix_per_slice;
+        const uint32_t npix = min(sl.pix_per_slice, ps.n_pixels - pix0);
+        const uint32_t n_paths = npix * ps.samples;
+
+        uint32_t lid = PT_NO_PRIM;          // path of the slice this lane holds (sample * npix + pixel)
+        int32_t bounce = 0;
+        v3 T = V(1.0f, 1.0f, 1.0f);         // throughput of the path so far
+        int32_t node = PT_TRAVERSAL_DONE;   // inner node (>= 0), the rest of a leaf (< 0), or no traversal under way
+        uint32_t sp = 0;
+        Ray r;
+        r.o = V(0.0f, 0.0f, 0.0f);
+        r.d = V(1.0f, 1.0f, 1.0f);
+        BoxRay br = make_box_ray(r, sc.cone.kappa_max);
+        Nearest nh;
+        nh.reset(t_max);
+        bool overflow = false;  // this ray's stack ran out (cannot happen; resolved by the list scan if it does)
+        bool exhausted = false; // wave-uniform: the slice has no unstarted path left
+        auto start_ray = [&]() {
+            br = make_box_ray(r, ray_kappa(sc.cone, r.o));
+            nh.reset(t_max);
+            overflow = false;
+            sp = 0;
+            node = 0; // root
+            rays++;
+        };
+        for (;;) {
+            const bool resting = node == PT_TRAVERSAL_DONE;
+            const bool to_shade = resting && lid != PT_NO_PRIM;
+            const bool empty = lid == PT_NO_PRIM;
+            const uint32_t n_shade = (uint32_t)__popcll(__ballot(to_shade));
+            const uint32_t n_empty = exhausted ? 0u : (uint32_t)__popcll(__ballot(empty));
+            const bool nobody_traverses = __ballot(!resting) == 0ull;
+            if (n_shade + n_empty >= serve_min || nobody_traverses) {
+                if (to_shade) { // main.cu:54-64 for the ray just traced
+                    bool need_exact = overflow;
+                    settle_parked<CONES>(nh, need_exact);
+                    HitResult h;
+                    h.t = nh.best_t;
+                    h.slot = nh.best_slot;
+                    if (need_exact) {
+                        if (CONES && !overflow) {
+                            h = bvh_exact_scan<BLOCK>(gsrc, sc.stack_cap, r, br, t_min, t_max, stack, need_exact);
+                            nr++;
+                        }
+                        if (need_exact) { // more candidates than the replay keeps: the list itself
+                            h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+                            if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
+                            nf++;
+                        }
+                    }
+                    bool go_on = false;
+                    v3 result;
+                    if (h.slot == PT_NO_PRIM) {
+                        result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
+                    } else {
+                        const PrimRec q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
+                        const uint32_t s = lid / npix, pl = lid - s * npix;
+                        Ray nray;
+                        v3 nT;
+                        go_on = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, bounce, q, h.t, nray, nT, result);
+                        if (go_on) {
+                            r = nray;
+                            T = nT;
+                            bounce++;
+                            start_ray();
+                        }
+                    }
+                    if (!go_on) {
+                        rad[3 * lid + 0] = result.x;
+                        rad[3 * lid + 1] = result.y;
+                        rad[3 * lid + 2] = result.z;
+                        lid = PT_NO_PRIM;
+                    }
+                }
+                if (!exhausted) { // lanes without a path take the slice's next ones
+                    const bool need = lid == PT_NO_PRIM;
+                    const unsigned long long m = __ballot(need);
+                    if (m) {
+                        const int first = __ffsll((long long)m) - 1;
+                        const uint32_t cnt_m = (uint32_t)__popcll(m);
+                        uint32_t base = 0;
+                        if (lane == (uint32_t)first) base = atomicAdd(&s_next, cnt_m);
+                        base = __shfl(base, first, 64);
+                        const uint32_t mine = base + lane_prefix(m);
+                        if (need && mine < n_paths) {
+                            lid = mine;
+                            const uint32_t s = mine / npix, pl = mine - s * npix;
+                            r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s); // main.cu:88-92
+                            T = V(1.0f, 1.0f, 1.0f);
+                            bounce = 0;
+                            start_ray();
+                        }
+                        exhausted = base + cnt_m >= n_paths;
+                    }
+                }
+                if (__ballot(lid != PT_NO_PRIM) == 0ull) break; // no path left in this wave, none to take
+                continue;
+            }
+            if (node != PT_TRAVERSAL_DONE) {
+                const bool inner = node >= 0;
+                const uint32_t ref = (uint32_t)~node; // leaf: (first object << 3) | (objects left - 1)
+                const float4 *rec = inner ? reinterpret_cast<const float4 *>(sc.nodes + node)
+                                          : reinterpret_cast<const float4 *>(sc.prims + (ref >> 3));
+                const float4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3]; // (the object array is padded by one record)
+                if (inner) {
+                    float2 nx, ny, nz, fx, fy, fz;
+                    int32_t c0, c1;
+                    planes_of_record(w0, w1, w2, w3, br, nx, ny, nz, fx, fy, fz, c0, c1);
+                    float tn0, tn1;
+                    bool h0, h1;
+                    box_test2(nx, ny, nz, fx, fy, fz, br, t_min, nh.best_t, h0, h1, tn0, tn1);
+                    if (COUNT) nb += 2;
+                    if (h0 && h1) {
+                        const bool swap = tn1 < tn0;
+                        if (sp < sc.stack_cap) stack[(sp++) * BLOCK] = (uint32_t)(swap ? c0 : c1);
+                        else overflow = true;
+                        node = swap ? c1 : c0;
+                    } else if (h0) {
+                        node = c0;
+                    } else if (h1) {
+                        node = c1;
+                    } else {
+                        node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
+                    }
+                } else {
+                    const uint32_t first = ref >> 3, left = (ref & 7u) + 1u;
+                    PrimRec q;
+                    q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                    q.meta = __float_as_uint(w1.z);
+                    q.id = __float_as_uint(w1.w);
+                    object_test<CONES>(q, first, r, t_min, t_max, nh);
+                    if (left > 1) {
+                        q.p[0] = w2.x; q.p[1] = w2.y; q.p[2] = w2.z; q.p[3] = w2.w; q.p[4] = w3.x; q.p[5] = w3.y;
+                        q.meta = __float_as_uint(w3.z);
+                        q.id = __float_as_uint(w3.w);
+                        object_test<CONES>(q, first + 1u, r, t_min, t_max, nh);
+                    }
+                    if (COUNT) np += left > 1 ? 2u : 1u;
+                    if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
+                    else node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
+                }
+            }
+        }
+        // film: col += ray_color(...) in sample order (main.cu:93) for the slice's pixels
+        __syncthreads();
+        for (uint32_t pl = threadIdx.x; pl < npix; pl += BLOCK) {
+            const size_t px = (size_t)(pix0 + pl) * 3;
+            float cr = rgb_sum[px], cg = rgb_sum[px + 1], cb = rgb_sum[px + 2];
+            for (uint32_t s = 0; s < ps.samples; ++s) {
+                const uint32_t id = s * npix + pl;
+                cr += rad[3 * id];
+                cg += rad[3 * id + 1];
+                cb += rad[3 * id + 2];
+            }
+            rgb_sum[px] = cr;
+            rgb_sum[px + 1] = cg;
+            rgb_sum[px + 2] = cb;
+        }
+    }
+    rays = wave_sum_u32((uint32_t)rays);
+    if (lane == 0 && rays) atomicAdd(&cnt->rays, rays);
+    if (COUNT) {
+        unsigned long long sb = wave_sum_u32(nb), sp2 = wave_sum_u32(np);
+        if (lane == 0) {
+            atomicAdd(&cnt->box_tests, sb);
+            atomicAdd(&cnt->prim_tests, sp2);
+        }
+    }
+    if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
+    if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
+}
+
 // col += ray_color(...) in sample order (main.cu:93), and the pass's ray count.
 __global__ __launch_bounds__(PT_BLOCK) void k_film(PassDev ps, const float *__restrict__ rad, float *__restrict__ rgb_sum,
                                                    const uint32_t *__restrict__ n_active, Counters *cnt)
@@ -1387,7 +1698,8 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     free_scene(ctx);
     const size_t nb = b.nodes.size() * sizeof(BvhNode), pb = leaf.size() * sizeof(PrimRec), mb = mats.size() * sizeof(float4);
     PT_HIP(ctx, hipMalloc(&ctx->d_nodes, nb));
-    PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb));
+    PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb + sizeof(PrimRec))); // one record of padding: k_paths_stream fetches objects in pairs
+    PT_HIP(ctx, hipMemset(reinterpret_cast<char *>(ctx->d_prims) + pb, 0, sizeof(PrimRec)));
     PT_HIP(ctx, hipMalloc(&ctx->d_prims_list, pb));
     PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
     PT_HIP(ctx, hipMemcpy(ctx->d_nodes, b.nodes.data(), nb, hipMemcpyHostToDevice));
@@ -1578,18 +1890,23 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
     const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
     const bool want_lds = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0 && env_int("PT_PATHS_LDS", 1) != 0;
-    int block = env_int("PT_PATHS_BLOCK", 512);
-    if (block != 256 && block != 512) block = 512;
     const bool sort = (pr->flags & PT_RENDER_NO_SORT) == 0 && env_int("PT_PATHS_SORT", 0) != 0; // measured slower on the spheres scene: opt-in
     const SceneDev &sc = ctx->sc;
-    const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
     const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32;
+    int block = env_int("PT_PATHS_BLOCK", 0);
+    if (block != 256 && block != 512) // LDS-resident scenes: 512 (one scene copy per 8 waves); HBM scenes: 256 measured best
+        block = want_lds && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024 ? 512 : 256;
+    const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
     bool lds = want_lds && scene_bytes + stack_bytes <= 64 * 1024;
     const size_t lds_bytes = stack_bytes + (lds ? scene_bytes : 0);
+    // scenes traversed from HBM take the streaming kernel (PT_PATHS_STREAM overrides)
+    const bool stream_kernel = !sort && env_int("PT_PATHS_STREAM", lds ? 0 : 1) != 0;
     int per_cu = env_int("PT_PATHS_PER_CU", 0);
     if (per_cu <= 0) {
         const size_t static_lds = 64 + (sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
-        per_cu = std::min<int>(2048 / block, (int)((160 * 1024) / std::max<size_t>(lds_bytes + static_lds, 1)));
+        const size_t lds_used = (stream_kernel ? stack_bytes : lds_bytes) + static_lds;
+        const int waves_per_simd = stream_kernel ? PT_STREAM_WAVES : 6; // the kernels' register budgets
+        per_cu = std::min<int>(waves_per_simd * 4 * 64 / block, (int)((160 * 1024) / std::max<size_t>(lds_used, 1)));
         per_cu = std::max(per_cu, 1);
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
@@ -1631,13 +1948,22 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
     sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.ticket = ctx->d_ticket;
+    const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 16)));
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (stream_kernel) {
+            const bool cones = ctx->has_cones;
+#define PT_LAUNCH_REFILL(C, B, K) hipLaunchKernelGGL((k_paths_stream<C, B, K>), dim3(grid), dim3(B), stack_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt, serve_min)
+#define PT_LAUNCH_REFILL_B(C, K) do { if (block == 256) PT_LAUNCH_REFILL(C, 256, K); else PT_LAUNCH_REFILL(C, 512, K); } while (0)
+            if (count) { if (cones) PT_LAUNCH_REFILL_B(true, true); else PT_LAUNCH_REFILL_B(true, false); }
+            else { if (cones) PT_LAUNCH_REFILL_B(false, true); else PT_LAUNCH_REFILL_B(false, false); }
+#undef PT_LAUNCH_REFILL_B
+#undef PT_LAUNCH_REFILL
+        } else if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         else launch_paths<false>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }

@@ -67,10 +67,17 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
         img, s2 = ctx.render(w, h, spp, depth, **kw)
         assert s2["rays"] == st["rays"], tag
         assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tag
-    for env in ({"PT_PATHS_BLOCK": "256"}, {"PT_PATHS_SORT": "1"}, {"PT_PATHS_SLICE": "4096"}, {"PT_PATHS_SLICE": "1000000"}):
+    for env in ({"PT_PATHS_BLOCK": "256"}, {"PT_PATHS_SORT": "1"}, {"PT_PATHS_SLICE": "4096"}, {"PT_PATHS_SLICE": "1000000"},
+                # scene in HBM: the streaming kernel (default there) at several batching thresholds and
+                # workgroup sizes, and the queue-based slice kernel
+                {"hbm": "1", "PT_PATHS_STREAM_MIN": "1"}, {"hbm": "1", "PT_PATHS_STREAM_MIN": "64"},
+                {"hbm": "1", "PT_PATHS_BLOCK": "512"}, {"hbm": "1", "PT_PATHS_STREAM": "0"},
+                {"PT_PATHS_STREAM": "1"}):
+        env = dict(env)
+        flags = api.RENDER_NO_LDS_SCENE if env.pop("hbm", None) else 0
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        img, s2 = ctx.render(w, h, spp, depth)
+        img, s2 = ctx.render(w, h, spp, depth, flags=flags)
         for k in env:
             monkeypatch.delenv(k)
         assert s2["rays"] == st["rays"], env
