@@ -29,8 +29,8 @@ WORKLOADS = {
     "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50, B=2.00, P=3.09),
     "c2": dict(name="random-spheres (485 spheres) 1920x1080 64spp depth50", scene=scenes.random_spheres_scene, w=1920, h=1080, spp=64, depth=50, B=16.78, P=4.01),
     "c3": dict(name="cornell box 1024x1024 1024spp depth50", scene=scenes.cornell_scene, w=1024, h=1024, spp=1024, depth=50, B=3.98, P=4.85),
-    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50, B=59.21, P=7.23),
-    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50, B=73.95, P=8.18),
+    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50, B=58.98, P=25.73),
+    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50, B=74.09, P=27.74),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
 VALU_PEAK_TFLOPS = 78.6     # fp32 vector peak WITHOUT packed v_pk_fma (half of the 157.3 spec figure)

@@ -1517,6 +1517,16 @@ static int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
+// lose 10-20 %); scenes traversed from HBM pay per record fetched, and two objects come with every 64-byte
+// fetch: 8 per leaf is 5-15 % faster than 4 there (100k objects 129 -> 122 ms, 1M spheres 367 -> 312 ms).
+// PT_LEAF_MAX overrides (tuning).
+static uint32_t leaf_max_for(const pt_scene_desc *desc)
+{
+    if (const char *v = getenv("PT_LEAF_MAX")) return (uint32_t)atoi(v);
+    return desc->n_prims > 1000u ? 8u : (uint32_t)PT_LEAF_MAX;
+}
+
 static pt_status fail(pt_context *ctx, pt_status st, const std::string &msg)
 {
     if (ctx) ctx->err = msg;
@@ -1653,7 +1663,7 @@ extern "C" pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_no
     std::string e = validate_desc(desc);
     if (!e.empty()) return PT_ERR_INVALID;
     pt::BvhBuild b;
-    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
     if (!e.empty()) return PT_ERR_INVALID;
     if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
     if (max_depth) *max_depth = b.max_depth;
@@ -1668,7 +1678,7 @@ extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *o
     std::string e = validate_desc(desc);
     if (!e.empty()) return PT_ERR_INVALID;
     pt::BvhBuild b;
-    e = pt::build_bvh(*desc, PT_LEAF_MAX, b);
+    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
     if (!e.empty()) return PT_ERR_INVALID;
     out->kappa_max = b.cone.kappa_max;
     out->kappa_min = b.cone.kappa_min;
@@ -1685,7 +1695,7 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     std::string e = validate_desc(desc);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     pt::BvhBuild b;
-    const uint32_t leaf_max = getenv("PT_LEAF_MAX") ? (uint32_t)atoi(getenv("PT_LEAF_MAX")) : PT_LEAF_MAX; // tuning knob
+    const uint32_t leaf_max = leaf_max_for(desc);
     e = pt::build_bvh(*desc, leaf_max, b);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     if (b.max_depth > 96) return fail(ctx, PT_ERR_LIMIT, "BVH deeper than 96 levels");

@@ -51,7 +51,8 @@ def test_camera_bit_exact_against_oracle(builder):
     assert lib_cam["lens_radius"] == orc_cam["lens_radius"]
 
 
-def _check_tree(desc, nodes, order, leaf_max=4):
+def _check_tree(desc, nodes, order, leaf_max=None):
+    leaf_max = leaf_max or (8 if desc.c.n_prims > 1000 else 4)  # larger leaves for scenes traversed from HBM
     n = desc.c.n_prims
     assert sorted(order.tolist()) == list(range(n))  # every object in exactly one leaf slot
     seen = np.zeros(n, bool)
@@ -104,7 +105,7 @@ def test_bvh_invariants(builder):
     depth = _check_tree(d, nodes, order)
     assert depth == max_depth and max_depth <= 64
     if d.c.n_prims > 4:
-        assert len(nodes) >= d.c.n_prims // 4 - 1
+        assert len(nodes) >= d.c.n_prims // (8 if d.c.n_prims > 1000 else 4) - 1
 
 
 def test_bvh_degenerate_inputs():
