@@ -23,7 +23,7 @@ import torch  # noqa: E402
 
 from pathtracer_amd import api, distributed, scenes  # noqa: E402
 
-# Workloads named by BASELINE.json's configs.  B / P: mean box and object tests per ray, measured
+# The benchmark configurations of BASELINE.json.  B / P: mean box and object tests per ray, measured
 # once with PT_RENDER_COUNT_TESTS on the library's tree (binned SAH, 16 bins, leaf <= 4) and frozen.
 WORKLOADS = {
     "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50, B=2.00, P=3.09),

@@ -1,4 +1,4 @@
-"""Ad-hoc: the other BASELINE workloads at reduced spp (timing, ray statistics, fallbacks)."""
+"""Ad-hoc: the other benchmark workloads at reduced spp (timing, ray statistics, fallbacks)."""
 import sys, time
 sys.path.insert(0, ".")
 from pathtracer_amd import api, scenes

@@ -281,9 +281,9 @@ def test_render_device_accumulates(ctx):
 @pytest.mark.parametrize("which", ["mixed_100k", "spheres_1m"])
 def test_large_scene_trace_bit_exact(ctx, which):
     if which == "mixed_100k":
-        b, n = scenes.mixed_scene(), 1500          # BASELINE config 4's scene (cones included)
+        b, n = scenes.mixed_scene(), 1500          # benchmark configuration 4's scene (cones included)
     else:
-        b, n = scenes.sphere_slab_scene(), 300     # BASELINE config 5's scene
+        b, n = scenes.sphere_slab_scene(), 300     # benchmark configuration 5's scene
     ctx.upload(b.desc())
     osc = util.oracle_scene(b)
     o, d = util.mixed_rays(b, osc, n, seed=55)
@@ -299,7 +299,7 @@ def test_large_scene_trace_bit_exact(ctx, which):
 
 @pytest.mark.parametrize("which", ["mixed_100k", "spheres_1m"])
 def test_large_scene_render_crop(ctx, which):
-    """BASELINE configs 4 and 5: their scenes at 4K, 1 spp; a crop against the oracle (which renders only
+    """Benchmark configurations 4 and 5: their scenes at 4K, 1 spp; a crop against the oracle (which renders only
     those pixels: the stream is keyed by the absolute pixel index), finite images and sane counters for
     the full frame."""
     if which == "mixed_100k":

@@ -78,7 +78,7 @@ def _image_close(got, ref):
 
 @pytest.mark.parametrize("depth", [5, 50])
 def test_render_default_scene(ctx, depth):
-    """BASELINE config 1: scene() at 400x225, 16 spp; depth 5 is the reference's own (main.cu:93)."""
+    """benchmark configuration 1: scene() at 400x225, 16 spp; depth 5 is the reference's own (main.cu:93)."""
     b = scenes.default_scene()
     ctx.upload(b.desc())
     osc = util.oracle_scene(b)
@@ -102,7 +102,7 @@ def test_render_small(ctx, name, w, h, spp, depth):
 
 
 def test_render_full_size_crop(ctx):
-    """BASELINE config 2 at its full 1920x1080 size (2 spp): a 48x32 crop against the oracle, which
+    """benchmark configuration 2 at its full 1920x1080 size (2 spp): a 48x32 crop against the oracle, which
     renders only those pixels (the stream is keyed by the absolute pixel index)."""
     b = scenes.random_spheres_scene()
     ctx.upload(b.desc())
