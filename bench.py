@@ -160,14 +160,15 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "k_paths", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_paths" if len(builder.arrays()["prim_type"]) <= 1000 else "k_paths_stream", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_ray": bpr, "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
             "valu": {"achieved_tflops": fpr * rays_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0,
                      "peak_tflops": VALU_PEAK_TFLOPS, "peak_kind": "fp32 vector, non-packed", "flops_per_ray": fpr},
             "note": "algorithmic bytes (32B+32P+100 per ray) over event-timed k_paths launches; for cache-resident scenes the "
-                    "figure is a rate of useful bytes, not HBM traffic (see `traffic`, from rocprofv3 PMC passes); the kernel "
-                    "is VALU-issue-bound (profiles/)",
+                    "figure is a rate of useful bytes, not HBM traffic (see `traffic`, from rocprofv3 PMC passes); on the "
+                    "LDS-resident scenes the kernel is VALU-issue-bound (profiles/r01_pmc_c2.json), on the large ones bound "
+                    "by scattered 64-byte L2 misses",
         }
         if cnt is not None and cnt["rays"]:
             roofline["measured_B"] = cnt["box_tests"] / cnt["rays"]
