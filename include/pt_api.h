@@ -124,6 +124,13 @@ pt_status pt_camera_look_at(const float lookfrom[3], const float lookat[3], cons
  * cylinder.h:133-138) and copies everything to the device. */
 pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc);
 
+/* A changed scene with the same number of objects (moved or resized objects, other types or materials,
+ * another camera or background): keeps the uploaded scene's tree and refits its boxes, O(objects), instead
+ * of rebuilding it.  The reference has no counterpart -- it rebuilds its whole scene per run (scene.h:20-58,
+ * main.cu:157-186) -- and no hierarchy to keep.  Answers are those of a fresh pt_scene_upload of `desc`
+ * (the list scan's, bit for bit); only the traversal cost follows how far the objects moved. */
+pt_status pt_scene_update(pt_context *ctx, const pt_scene_desc *desc);
+
 /* hittable_list::hit (hittable_list.h:87-101) for n rays.  o_xyz / d_xyz / out are host buffers.
  * mode PT_TRACE_BVH is the production traversal, PT_TRACE_LINEAR the list-order scan on the GPU.
  * PT_TRACE_BVH_IN_SCENE is the traversal exactly as pt_render runs it: the caller asserts that every
@@ -156,6 +163,11 @@ pt_status pt_film_finalize(const float *rgb_sum, int32_t width, int32_t height, 
  * indices in leaf order.  Pass NULLs to query the sizes. */
 pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
                             uint32_t *order_out);
+
+/* The tree pt_scene_update leaves behind (host-side tests, no GPU needed): built for `before`, refitted to
+ * `after` (same number of objects).  Outputs as for pt_bvh_build_host. */
+pt_status pt_bvh_refit_host(const pt_scene_desc *before, const pt_scene_desc *after, uint32_t *n_nodes, uint32_t *max_depth,
+                            void *nodes_out, uint32_t *order_out);
 
 /* How wide a cone the traversal gives its rays in this scene (host-side tests, no GPU needed).  The
  * reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) accept hits up to

@@ -22,9 +22,9 @@ NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
 EXPORTS = [
-    "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload",
+    "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload", "pt_scene_update",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
-    "pt_bvh_build_host", "pt_scene_ray_cone", "pt_version",
+    "pt_bvh_build_host", "pt_bvh_refit_host", "pt_scene_ray_cone", "pt_version",
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
         L.pt_context_destroy.argtypes = [C.c_void_p]
         L.pt_context_destroy.restype = None
         L.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
+        L.pt_scene_update.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
         L.pt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.pt_trace_rays_device.argtypes = L.pt_trace_rays.argtypes + [C.c_void_p]
         L.pt_render.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.POINTER(PtStats)]
@@ -127,6 +128,7 @@ def lib():
         L.pt_camera_look_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(PtCamera)]
         L.pt_bvh_build_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.pt_scene_ray_cone.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRayCone)]
+        L.pt_bvh_refit_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -194,6 +196,20 @@ def bvh_build_host(desc):
     return nodes, order, depth.value
 
 
+def bvh_refit_host(before, after):
+    """The tree pt_scene_update leaves: built for `before`, refitted to `after`; returns (nodes, order, max_depth)."""
+    n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+    st = lib().pt_bvh_refit_host(C.byref(before.c), C.byref(after.c), C.byref(n_nodes), C.byref(depth), None, None)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_refit_host")
+    nodes = np.zeros(n_nodes.value, dtype=NODE_DTYPE)
+    order = np.zeros(after.c.n_prims, dtype=np.uint32)
+    st = lib().pt_bvh_refit_host(C.byref(before.c), C.byref(after.c), C.byref(n_nodes), C.byref(depth), nodes.ctypes.data, order.ctypes.data)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_refit_host")
+    return nodes, order, depth.value
+
+
 def scene_ray_cone(desc):
     """pt_scene_ray_cone as a dict (host only)."""
     out = PtRayCone()
@@ -249,6 +265,10 @@ class Context:
 
     def upload(self, desc):
         self._check(lib().pt_scene_upload(self._h, C.byref(desc.c)))
+
+    def update(self, desc):
+        """pt_scene_update: a changed scene with the same number of objects; the tree is refitted, not rebuilt."""
+        self._check(lib().pt_scene_update(self._h, C.byref(desc.c)))
 
     def trace(self, o, d, t_min=0.001, t_max=FLT_MAX, mode=TRACE_BVH):
         o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)

@@ -203,14 +203,13 @@ bool prim_box(uint8_t type, const float *q, float kappa, float extra, Box &b)
     return true;
 }
 
-std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
+// The ray cone of the scene and every object's padded box (what a build and a refit share).
+static std::string cone_and_boxes(const pt_scene_desc &d, ConeParams &cp, std::vector<Box> &boxes)
 {
     if (d.n_prims == 0) return "scene has no objects";
     if (d.n_prims >= (1u << 28)) return "too many objects (limit 2^28 - 1)";
-    if (leaf_max < 1 || leaf_max > 8) return "leaf_max must be 1..8";
-    ConeParams &cp = out.cone;
     cp = ConeParams();
-    std::vector<Box> boxes(d.n_prims);
+    boxes.resize(d.n_prims);
     // exact volumes first: the scene's extent decides which objects can carry their own padding
     Box root;
     box_empty(root);
@@ -274,6 +273,15 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
     }
     for (uint32_t i = 0; i < d.n_prims; ++i) // an object that carries its own padding needs no share of the cone's
         prim_box(d.prim_type[i], d.prim_param + (size_t)i * 6, extra[i] > 0.0f ? 0.0f : cp.kappa_max, extra[i], boxes[i]);
+    return "";
+}
+
+std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
+{
+    if (leaf_max < 1 || leaf_max > 8) return "leaf_max must be 1..8";
+    std::vector<Box> boxes;
+    const std::string e = cone_and_boxes(d, out.cone, boxes);
+    if (!e.empty()) return e;
     out.order.resize(d.n_prims);
     std::iota(out.order.begin(), out.order.end(), 0u);
     out.nodes.clear();
@@ -294,6 +302,38 @@ std::string build_bvh(const pt_scene_desc &d, uint32_t leaf_max, BvhBuild &out)
         b.max_depth = 1;
     }
     out.max_depth = b.max_depth;
+    return "";
+}
+
+std::string refit_bvh(const pt_scene_desc &d, BvhBuild &bvh)
+{
+    if (bvh.order.size() != d.n_prims || bvh.nodes.empty()) return "refit needs the tree of a scene with the same number of objects";
+    std::vector<Box> boxes;
+    const std::string e = cone_and_boxes(d, bvh.cone, boxes);
+    if (!e.empty()) return e;
+    // Children are created after their parent (build_inner), so a reverse sweep sees every child's box
+    // before the node that holds it.
+    std::vector<Box> own(bvh.nodes.size());
+    for (size_t k = bvh.nodes.size(); k-- > 0;) {
+        HostNode &n = bvh.nodes[k];
+        Box me;
+        box_empty(me);
+        for (int child = 0; child < 2; ++child) {
+            if (!(n.b[0][child] < kInf)) continue; // absent child (single-leaf scenes): stays a point at infinity
+            Box cb;
+            box_empty(cb);
+            const int32_t ref = n.c[child];
+            if (ref >= 0) {
+                cb = own[(size_t)ref];
+            } else {
+                const uint32_t r = (uint32_t)~ref, first = r >> 3, count = (r & 7u) + 1u;
+                for (uint32_t s = first; s < first + count; ++s) box_grow(cb, boxes[bvh.order[s]]);
+            }
+            for (int a = 0; a < 3; ++a) { n.b[a][child] = cb.lo[a]; n.b[a][2 + child] = cb.hi[a]; }
+            box_grow(me, cb);
+        }
+        own[k] = me;
+    }
     return "";
 }
 

@@ -70,4 +70,8 @@ bool prim_box(uint8_t type, const float *param, float kappa, float extra, Box &o
 // Binned SAH (16 bins per axis), leaves of at most leaf_max objects.  Returns "" or an error text.
 std::string build_bvh(const pt_scene_desc &desc, uint32_t leaf_max, BvhBuild &out);
 
+// Same topology, new boxes: for a scene whose objects moved or changed size (same count, any types).  O(N);
+// the tree's quality follows the motion, its answers do not depend on it.
+std::string refit_bvh(const pt_scene_desc &desc, BvhBuild &bvh);
+
 } // namespace pt

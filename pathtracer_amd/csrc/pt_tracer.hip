@@ -1486,6 +1486,8 @@ struct pt_context {
     PrimRec *d_prims = nullptr, *d_prims_list = nullptr;
     float4 *d_mats = nullptr;
     uint32_t max_depth_tree = 0;
+    pt::BvhBuild tree;      // the installed scene's tree (host copy), refitted by pt_scene_update
+    size_t n_mats_alloc = 0;
     bool has_cones = false; // the scene holds at least one cone: the only object whose answer can depend on list order
     bool lds_scene = true; // traverse small scenes from LDS (PT_RENDER_NO_LDS_SCENE turns it off for A/B runs)
 
@@ -1672,6 +1674,20 @@ extern "C" pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_no
     return PT_OK;
 }
 
+extern "C" pt_status pt_bvh_refit_host(const pt_scene_desc *before, const pt_scene_desc *after, uint32_t *n_nodes, uint32_t *max_depth,
+                                       void *nodes_out, uint32_t *order_out)
+{
+    if (!validate_desc(before).empty() || !validate_desc(after).empty()) return PT_ERR_INVALID;
+    pt::BvhBuild b;
+    if (!pt::build_bvh(*before, leaf_max_for(before), b).empty()) return PT_ERR_INVALID;
+    if (!pt::refit_bvh(*after, b).empty()) return PT_ERR_INVALID;
+    if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
+    if (max_depth) *max_depth = b.max_depth;
+    if (nodes_out) memcpy(nodes_out, b.nodes.data(), b.nodes.size() * sizeof(pt::HostNode));
+    if (order_out) memcpy(order_out, b.order.data(), b.order.size() * sizeof(uint32_t));
+    return PT_OK;
+}
+
 extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *out)
 {
     if (!out) return PT_ERR_INVALID;
@@ -1689,15 +1705,10 @@ extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *o
     return PT_OK;
 }
 
-extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
+// Copies a built (or refitted) tree and the scene's records to the device and points the context at them.
+// `fresh` allocates; otherwise the buffers of the previous upload (same object count) are overwritten.
+static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const pt::BvhBuild &b, bool fresh)
 {
-    if (!ctx) return PT_ERR_INVALID;
-    std::string e = validate_desc(desc);
-    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
-    pt::BvhBuild b;
-    const uint32_t leaf_max = leaf_max_for(desc);
-    e = pt::build_bvh(*desc, leaf_max, b);
-    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     if (b.max_depth > 96) return fail(ctx, PT_ERR_LIMIT, "BVH deeper than 96 levels");
     std::vector<PrimRec> leaf, list;
     std::vector<float4> mats;
@@ -1705,13 +1716,21 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
 
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipDeviceSynchronize());
-    free_scene(ctx);
     const size_t nb = b.nodes.size() * sizeof(BvhNode), pb = leaf.size() * sizeof(PrimRec), mb = mats.size() * sizeof(float4);
-    PT_HIP(ctx, hipMalloc(&ctx->d_nodes, nb));
-    PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb + sizeof(PrimRec))); // one record of padding: k_paths_stream fetches objects in pairs
-    PT_HIP(ctx, hipMemset(reinterpret_cast<char *>(ctx->d_prims) + pb, 0, sizeof(PrimRec)));
-    PT_HIP(ctx, hipMalloc(&ctx->d_prims_list, pb));
-    PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
+    if (fresh) {
+        free_scene(ctx);
+        PT_HIP(ctx, hipMalloc(&ctx->d_nodes, nb));
+        PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb + sizeof(PrimRec))); // one record of padding: k_paths_stream fetches objects in pairs
+        PT_HIP(ctx, hipMemset(reinterpret_cast<char *>(ctx->d_prims) + pb, 0, sizeof(PrimRec)));
+        PT_HIP(ctx, hipMalloc(&ctx->d_prims_list, pb));
+        PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
+        ctx->n_mats_alloc = mats.size();
+    } else if (mats.size() > ctx->n_mats_alloc) {
+        hipFree(ctx->d_mats);
+        ctx->d_mats = nullptr;
+        PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
+        ctx->n_mats_alloc = mats.size();
+    }
     PT_HIP(ctx, hipMemcpy(ctx->d_nodes, b.nodes.data(), nb, hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->d_prims, leaf.data(), pb, hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->d_prims_list, list.data(), pb, hipMemcpyHostToDevice));
@@ -1743,6 +1762,36 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     ctx->has_cones = false;
     for (uint32_t i = 0; i < desc->n_prims; ++i) ctx->has_cones |= desc->prim_type[i] == PT_CONE;
     ctx->has_scene = true;
+    return PT_OK;
+}
+
+extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    pt::BvhBuild b;
+    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    const pt_status st = install_scene(ctx, desc, b, true);
+    if (st != PT_OK) return st;
+    ctx->tree = std::move(b); // kept for pt_scene_update
+    return PT_OK;
+}
+
+extern "C" pt_status pt_scene_update(pt_context *ctx, const pt_scene_desc *desc)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    if (desc->n_prims != ctx->sc.n_prims) return fail(ctx, PT_ERR_INVALID, "pt_scene_update needs the same number of objects as the uploaded scene");
+    pt::BvhBuild b = ctx->tree; // refit a copy: a failure leaves the installed scene as it was
+    e = pt::refit_bvh(*desc, b);
+    if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
+    const pt_status st = install_scene(ctx, desc, b, false);
+    if (st != PT_OK) return st;
+    ctx->tree = std::move(b);
     return PT_OK;
 }
 
