@@ -8,6 +8,8 @@
 #include "pt_oracle.h"
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -457,7 +459,12 @@ static v3 ray_color(const orc_scene *s, v3 o, v3 d, int depth, rng_t *g, uint32_
     if (depth <= 0) return V(0, 0, 0);
     ++*rays;
     memset(&rec, 0, sizeof rec);
-    if (!hit_list(s, o, d, 0.001f, FLT_MAX /* commons.h:11 */, &rec)) return vload(s->background);
+    int h = hit_list(s, o, d, 0.001f, FLT_MAX /* commons.h:11 */, &rec);
+    if (getenv("ORC_PRINT_PATH")) /* diagnostic: the path's rays and hits, one line per bounce */
+        fprintf(stderr, "[orc] bounce %u o %.9g %.9g %.9g d %.9g %.9g %.9g hit %d prim %u type %d t %.9g n %.9g %.9g %.9g front %d\n", bounce - 1,
+                o.e[0], o.e[1], o.e[2], d.e[0], d.e[1], d.e[2], h, h ? rec.prim : 0u, h ? (int)s->prim_type[rec.prim] : -1, rec.t, rec.n[0],
+                rec.n[1], rec.n[2], (int)rec.front);
+    if (!h) return vload(s->background);
     uint32_t mat = s->prim_material[rec.prim];
     v3 attenuation, so, sd;
     v3 emit = emitted(s, mat);

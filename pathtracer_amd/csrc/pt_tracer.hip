@@ -650,6 +650,58 @@ PT_DI unsigned long long wave_sum_u32(uint32_t v)
     return s; // valid in lane 0
 }
 
+// hittable_list::hit (hittable_list.h:87-101) for ONE ray by the whole wave: the same answer as
+// linear_nearest, 64 list entries at a time.  Every lane tests its entry against the running nearest t
+// as it stood at the start of the round; the first accepting lane is what the scan would accept next,
+// its t becomes the running value and the lanes after it are tested again.  A round per acceptance,
+// so a ray that a scan would update k times costs n/64 + k rounds.  Once the running value is a NaN
+// (a hit whose t is NaN is accepted by the reference's comparisons, and so is everything after it)
+// no test depends on it any more: all accepting lanes up to the first one with an ordinary t are then
+// what the scan accepts, and one round settles them.  All 64 lanes must call this together.
+static __device__ __forceinline__ unsigned long long wave_list_scan(const PrimRec *__restrict__ list, uint32_t n, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                                 float t_min, float t_max)
+{
+    Ray r;
+    r.o = V(ox, oy, oz);
+    r.d = V(dx, dy, dz);
+    const uint32_t lane = threadIdx.x & 63u;
+    HitResult best; // wave-uniform
+    best.t = t_max;
+    best.slot = PT_NO_PRIM;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const bool valid = base + lane < n;
+        const PrimRec q = list[valid ? base + lane : base];
+        uint32_t start = 0;
+        while (start < 64u) {
+            float t = 0.0f;
+            const bool acc = valid && lane >= start && hit_any(q, r, t_min, best.t, t);
+            const unsigned long long accepted = __ballot(acc);
+            if (!accepted) break;
+            int j = __ffsll((long long)accepted) - 1;
+            bool settled = false;
+            if (best.t != best.t) {
+                const unsigned long long ordinary = __ballot(acc && t == t);
+                if (ordinary) j = __ffsll((long long)ordinary) - 1;
+                else { j = 63 - __clzll((long long)accepted); settled = true; }
+            }
+            best.t = __shfl(t, j, 64);
+            best.slot = base + (uint32_t)j;
+            if (settled) break;
+            start = (uint32_t)j + 1u;
+        }
+    }
+    return ((unsigned long long)best.slot << 32) | __float_as_uint(best.t); // (registers, not memory, across the call)
+}
+// The same as a call.  Which form costs the calling kernel less is a matter of its register allocation:
+// k_paths_stream takes the call where its cone code already fills the register file (100k mixed objects:
+// 0.89 against 0.59 Grays/s inlined) and the inlined body otherwise (1M spheres: 1.07 against 0.95).
+static __device__ __attribute__((noinline)) unsigned long long wave_list_scan_call(const PrimRec *__restrict__ list, uint32_t n, float ox, float oy, float oz, float dx, float dy,
+                                                                                 float dz, float t_min, float t_max)
+{
+    return wave_list_scan(list, n, ox, oy, oz, dx, dy, dz, t_min, t_max);
+}
+
+
 PT_DI Ray load_ray_xyz(const float *o, const float *d, size_t i)
 {
     Ray r;
@@ -1256,31 +1308,45 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
 #ifndef PT_STREAM_WAVES
 #define PT_STREAM_WAVES 5
 #endif
+// One pass of k_paths_stream: `samples` samples (PassDev) of the pixels [pix0, pix0 + npix).
+struct BandDev {
+    uint32_t pix0, npix;
+    uint32_t tile; // pixels per tile of the path numbering (a multiple of 64)
+    uint32_t run;  // consecutive paths a wave takes at a time
+};
+
 template <bool COUNT, int BLOCK, bool CONES>
-__global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt,
+__global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
+                                                                           uint32_t *__restrict__ ticket, Counters *cnt,
                                                                            uint32_t serve_min /* lanes waiting for shading or a new path before they are served */)
 {
     extern __shared__ float4 s_mem[];
-    __shared__ uint32_t s_slice, s_next;
     uint32_t *const stack = reinterpret_cast<uint32_t *>(s_mem) + threadIdx.x;
     GlobalSrc gsrc{sc.nodes, sc.prims, sc.cone};
-    float *const rad = sl.rad + (size_t)blockIdx.x * 3 * sl.cap;
     const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long rays = 0;
     uint32_t nb = 0, np = 0, nf = 0, nr = 0;
-
-    for (;;) {
-        __syncthreads(); // previous slice's film pass is done with rad
-        if (threadIdx.x == 0) { s_slice = atomicAdd(sl.ticket, 1u); s_next = 0; }
-        __syncthreads();
-        const uint32_t slice = s_slice;
-        if (slice >= sl.n_slices) break;
-        const uint32_t pix0 = slice * sl.pix_per_slice;
-        const uint32_t npix = min(sl.pix_per_slice, ps.n_pixels - pix0);
-        const uint32_t n_paths = npix * ps.samples;
-
-        uint32_t lid = PT_NO_PRIM;          // path of the slice this lane holds (sample * npix + pixel)
+    // Paths are numbered tile by tile (`tile` neighbouring pixels) and within a tile sample by sample.  A
+    // wave owns a run of `run` consecutive paths at a time, fills its free lanes from it and takes the next
+    // run of the pass from one counter when it is used up; nothing else is shared between waves, and
+    // nothing waits for a run to finish.  The lanes of a wave therefore work on the samples of the same few
+    // pixels, whose rays meet the same part of the tree: with lanes filled from one pass-wide sequence
+    // instead, the 1M-sphere scene ran 25 % slower.
+    const uint32_t npix = band.npix;
+    const uint32_t n_paths = npix * ps.samples;
+    const uint32_t tile_paths = band.tile * ps.samples;
+    const uint32_t n_runs = (n_paths + band.run - 1) / band.run;
+    uint32_t run_next = 0, run_end = 0; // wave-uniform: what is left of the wave's run
+    // pixel within the band and sample within the pass of path p
+    auto path_of = [&](uint32_t p, uint32_t &pl, uint32_t &s) {
+        const uint32_t t = p / tile_paths, rem = p - t * tile_paths;
+        const uint32_t tp = min(band.tile, npix - t * band.tile); // the band's last tile may be short
+        s = rem / tp;
+        pl = t * band.tile + (rem - s * tp);
+    };
+    {
+        uint32_t lid = PT_NO_PRIM;          // where this lane's path reports: sample * npix + pixel within the band
         int32_t bounce = 0;
         v3 T = V(1.0f, 1.0f, 1.0f);         // throughput of the path so far
         int32_t node = PT_TRAVERSAL_DONE;   // inner node (>= 0), the rest of a leaf (< 0), or no traversal under way
@@ -1291,15 +1357,22 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
         BoxRay br = make_box_ray(r, sc.cone.kappa_max);
         Nearest nh;
         nh.reset(t_max);
-        bool overflow = false;  // this ray's stack ran out (cannot happen; resolved by the list scan if it does)
-        bool exhausted = false; // wave-uniform: the slice has no unstarted path left
+        bool by_list = false;   // this ray is answered by the list scan: non-finite ray, a hit at t = NaN, or its stack ran out (cannot happen)
+        bool exhausted = false; // wave-uniform: the pass has no unstarted path left
         auto start_ray = [&]() {
             br = make_box_ray(r, ray_kappa(sc.cone, r.o));
             nh.reset(t_max);
-            overflow = false;
+            by_list = false;
             sp = 0;
             node = 0; // root
             rays++;
+            // A ray with a NaN or infinite component (the reference accepts hits whose t is NaN, and the
+            // path goes on from a NaN point): the box test cannot prune for it, and what the scan accepts
+            // along it depends on list order throughout.  The list itself answers it.
+            if (!(fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(r.d.x) + fabsf(r.d.y) + fabsf(r.d.z) < PT_FLT_MAX)) {
+                by_list = true;
+                node = PT_TRAVERSAL_DONE;
+            }
         };
         for (;;) {
             const bool resting = node == PT_TRAVERSAL_DONE;
@@ -1309,23 +1382,38 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
             const uint32_t n_empty = exhausted ? 0u : (uint32_t)__popcll(__ballot(empty));
             const bool nobody_traverses = __ballot(!resting) == 0ull;
             if (n_shade + n_empty >= serve_min || nobody_traverses) {
-                if (to_shade) { // main.cu:54-64 for the ray just traced
-                    bool need_exact = overflow;
+                HitResult h;
+                h.t = nh.best_t;
+                h.slot = nh.best_slot;
+                bool scan_list = false;
+                if (to_shade) {
+                    bool need_exact = by_list;
                     settle_parked<CONES>(nh, need_exact);
-                    HitResult h;
                     h.t = nh.best_t;
                     h.slot = nh.best_slot;
                     if (need_exact) {
-                        if (CONES && !overflow) {
+                        if (CONES && !by_list) {
                             h = bvh_exact_scan<BLOCK>(gsrc, sc.stack_cap, r, br, t_min, t_max, stack, need_exact);
                             nr++;
                         }
-                        if (need_exact) { // more candidates than the replay keeps: the list itself
-                            h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
-                            if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
-                            nf++;
-                        }
+                        scan_list = need_exact; // by_list, or more candidates than the replay keeps
                     }
+                }
+                // the list itself, one such ray at a time by the whole wave
+                for (unsigned long long m = __ballot(scan_list); m; m &= m - 1ull) {
+                    const int j = __ffsll((long long)m) - 1;
+                    const float jox = __shfl(r.o.x, j, 64), joy = __shfl(r.o.y, j, 64), joz = __shfl(r.o.z, j, 64);
+                    const float jdx = __shfl(r.d.x, j, 64), jdy = __shfl(r.d.y, j, 64), jdz = __shfl(r.d.z, j, 64);
+                    const unsigned long long hj = CONES ? wave_list_scan_call(sc.prims_list, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max)
+                                                        : wave_list_scan(sc.prims_list, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max);
+                    if (lane == (uint32_t)j) {
+                        h.t = __uint_as_float((uint32_t)hj);
+                        h.slot = (uint32_t)(hj >> 32);
+                        if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
+                        nf++;
+                    }
+                }
+                if (to_shade) { // main.cu:54-64 for the ray just traced
                     bool go_on = false;
                     v3 result;
                     if (h.slot == PT_NO_PRIM) {
@@ -1335,7 +1423,7 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                         const uint32_t s = lid / npix, pl = lid - s * npix;
                         Ray nray;
                         v3 nT;
-                        go_on = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, bounce, q, h.t, nray, nT, result);
+                        go_on = shade_hit(sc.mats, ps, r, T, band.pix0 + pl, ps.sample_base + s, bounce, q, h.t, nray, nT, result);
                         if (go_on) {
                             r = nray;
                             T = nT;
@@ -1344,31 +1432,38 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                         }
                     }
                     if (!go_on) {
-                        rad[3 * lid + 0] = result.x;
-                        rad[3 * lid + 1] = result.y;
-                        rad[3 * lid + 2] = result.z;
+                        rad[3 * (size_t)lid + 0] = result.x;
+                        rad[3 * (size_t)lid + 1] = result.y;
+                        rad[3 * (size_t)lid + 2] = result.z;
                         lid = PT_NO_PRIM;
                     }
                 }
-                if (!exhausted) { // lanes without a path take the slice's next ones
+                if (!exhausted) { // lanes without a path take the next ones of the wave's run
                     const bool need = lid == PT_NO_PRIM;
                     const unsigned long long m = __ballot(need);
                     if (m) {
-                        const int first = __ffsll((long long)m) - 1;
-                        const uint32_t cnt_m = (uint32_t)__popcll(m);
-                        uint32_t base = 0;
-                        if (lane == (uint32_t)first) base = atomicAdd(&s_next, cnt_m);
-                        base = __shfl(base, first, 64);
-                        const uint32_t mine = base + lane_prefix(m);
-                        if (need && mine < n_paths) {
-                            lid = mine;
-                            const uint32_t s = mine / npix, pl = mine - s * npix;
-                            r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s); // main.cu:88-92
+                        if (run_next == run_end) { // the wave's run is used up: the next one of the pass
+                            uint32_t g = 0;
+                            if (lane == (uint32_t)(__ffsll((long long)m) - 1)) g = atomicAdd(ticket, 1u);
+                            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(g, __ffsll((long long)m) - 1, 64));
+                            if (g >= n_runs) {
+                                exhausted = true;
+                            } else {
+                                run_next = g * band.run;
+                                run_end = min(run_next + band.run, n_paths);
+                            }
+                        }
+                        const uint32_t k = lane_prefix(m);
+                        if (need && k < run_end - run_next) {
+                            uint32_t s, pl;
+                            path_of(run_next + k, pl, s);
+                            lid = s * npix + pl;
+                            r = camera_ray(sc.cam, ps, band.pix0 + pl, ps.sample_base + s); // main.cu:88-92
                             T = V(1.0f, 1.0f, 1.0f);
                             bounce = 0;
                             start_ray();
                         }
-                        exhausted = base + cnt_m >= n_paths;
+                        run_next += min((uint32_t)__popcll(m), run_end - run_next); // (lanes left without a path come back at once)
                     }
                 }
                 if (__ballot(lid != PT_NO_PRIM) == 0ull) break; // no path left in this wave, none to take
@@ -1391,7 +1486,7 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     if (h0 && h1) {
                         const bool swap = tn1 < tn0;
                         if (sp < sc.stack_cap) stack[(sp++) * BLOCK] = (uint32_t)(swap ? c0 : c1);
-                        else overflow = true;
+                        else by_list = true;
                         node = swap ? c1 : c0;
                     } else if (h0) {
                         node = c0;
@@ -1414,25 +1509,13 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                         object_test<CONES>(q, first + 1u, r, t_min, t_max, nh);
                     }
                     if (COUNT) np += left > 1 ? 2u : 1u;
-                    if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
+                    if (nh.best_t != nh.best_t) { // a hit at t = NaN was accepted: from here on the scan's answer is a matter of list order
+                        by_list = true;
+                        node = PT_TRAVERSAL_DONE;
+                    } else if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
                     else node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
                 }
             }
-        }
-        // film: col += ray_color(...) in sample order (main.cu:93) for the slice's pixels
-        __syncthreads();
-        for (uint32_t pl = threadIdx.x; pl < npix; pl += BLOCK) {
-            const size_t px = (size_t)(pix0 + pl) * 3;
-            float cr = rgb_sum[px], cg = rgb_sum[px + 1], cb = rgb_sum[px + 2];
-            for (uint32_t s = 0; s < ps.samples; ++s) {
-                const uint32_t id = s * npix + pl;
-                cr += rad[3 * id];
-                cg += rad[3 * id + 1];
-                cb += rad[3 * id + 2];
-            }
-            rgb_sum[px] = cr;
-            rgb_sum[px + 1] = cg;
-            rgb_sum[px + 2] = cb;
         }
     }
     rays = wave_sum_u32((uint32_t)rays);
@@ -1450,24 +1533,27 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
 
 // col += ray_color(...) in sample order (main.cu:93), and the pass's ray count.
 __global__ __launch_bounds__(PT_BLOCK) void k_film(PassDev ps, const float *__restrict__ rad, float *__restrict__ rgb_sum,
-                                                   const uint32_t *__restrict__ n_active, Counters *cnt)
+                                                   const uint32_t *__restrict__ n_active, Counters *cnt, uint32_t pix0 = 0, uint32_t npix = 0xFFFFFFFFu)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (n_active && blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long r = 0;
         for (int b = 0; b < ps.max_depth; ++b) r += n_active[b];
         atomicAdd(&cnt->rays, r);
     }
-    for (uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x; p < ps.n_pixels; p += gridDim.x * PT_BLOCK) {
-        float r = rgb_sum[3 * (size_t)p], g = rgb_sum[3 * (size_t)p + 1], b = rgb_sum[3 * (size_t)p + 2];
+    // rad holds [samples][npix] for the pixels [pix0, pix0 + npix) (all of them by default)
+    npix = min(npix, ps.n_pixels - pix0);
+    for (uint32_t pl = blockIdx.x * PT_BLOCK + threadIdx.x; pl < npix; pl += gridDim.x * PT_BLOCK) {
+        const size_t p = (size_t)pix0 + pl;
+        float r = rgb_sum[3 * p], g = rgb_sum[3 * p + 1], b = rgb_sum[3 * p + 2];
         for (uint32_t s = 0; s < ps.samples; ++s) {
-            size_t id = (size_t)s * ps.n_pixels + p;
+            size_t id = (size_t)s * npix + pl;
             r += rad[3 * id];
             g += rad[3 * id + 1];
             b += rad[3 * id + 2];
         }
-        rgb_sum[3 * (size_t)p] = r;
-        rgb_sum[3 * (size_t)p + 1] = g;
-        rgb_sum[3 * (size_t)p + 2] = b;
+        rgb_sum[3 * p] = r;
+        rgb_sum[3 * p + 1] = g;
+        rgb_sum[3 * p + 2] = b;
     }
 }
 
@@ -1506,6 +1592,9 @@ struct pt_context {
     float2 *d_sC = nullptr;
     float *d_srad = nullptr;
     uint32_t *d_ticket = nullptr;
+    // k_paths_stream: finished radiance of one pass, [samples][pixels][3]
+    float *d_prad = nullptr;
+    size_t cap_prad = 0; // paths
     // pt_trace_rays staging
     float *d_ro = nullptr, *d_rd = nullptr;
     pt_hit *d_rh = nullptr;
@@ -1570,6 +1659,7 @@ static void free_scene(pt_context *ctx)
 
 static void free_workspace(pt_context *ctx)
 {
+    hipFree(ctx->d_prad); ctx->d_prad = nullptr; ctx->cap_prad = 0;
     for (int k = 0; k < 2; ++k) { hipFree(ctx->d_A[k]); hipFree(ctx->d_B[k]); hipFree(ctx->d_C[k]); ctx->d_A[k] = ctx->d_B[k] = nullptr; ctx->d_C[k] = nullptr; }
     hipFree(ctx->d_hits); hipFree(ctx->d_rad); ctx->d_hits = nullptr; ctx->d_rad = nullptr;
     ctx->cap_paths = 0;
@@ -1970,6 +2060,93 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
 
+    if (stream_kernel) {
+        // One launch per pass: `spass` samples of a band of pixels.  The pass's finished radiance goes to a
+        // [samples][band pixels] buffer (1 GiB at most unless the caller fixes samples_per_pass) and k_film
+        // adds it to the film in sample order.  A frame that fits the buffer is one pass; otherwise passes of
+        // up to 256 samples go band by band, so that the samples of a pixel are traced close together in time.
+        const uint64_t budget_paths = (1ull << 30) / 12;
+        const uint32_t tile = (uint32_t)std::max(64, env_int("PT_STREAM_TILE", 64)) & ~63u;
+        uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::min(pr->spp, 256u);
+        spass = std::min(spass, pr->spp);
+        uint32_t band_pix = (uint32_t)std::min<uint64_t>(n_pixels, std::max<uint64_t>(tile, budget_paths / spass / tile * tile));
+        if ((uint64_t)spass * band_pix >= (1ull << 32) - (1ull << 24)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one pass"); // the path counter overshoots by up to 64 per wave
+        PT_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t need = (size_t)spass * band_pix;
+        if (need > ctx->cap_prad) {
+            hipFree(ctx->d_prad);
+            ctx->d_prad = nullptr; ctx->cap_prad = 0;
+            PT_HIP(ctx, hipMalloc(&ctx->d_prad, need * 3 * sizeof(float)));
+            ctx->cap_prad = need;
+        }
+        if (!ctx->d_ticket) PT_HIP(ctx, hipMalloc(&ctx->d_ticket, sizeof(uint32_t)));
+        StageTimer tm(ctx, stream, (pr->flags & PT_RENDER_STAGE_TIMES) != 0);
+        hipEvent_t ev0 = tm.get(), ev1 = tm.get();
+        PT_HIP(ctx, hipEventRecord(ev0, stream));
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
+        PassDev ps;
+        ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
+        ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
+        ps.max_depth = pr->max_depth;
+        const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 16)));
+        const bool cones = ctx->has_cones;
+        uint32_t n_passes = 0;
+        BandDev band;
+        band.tile = tile;
+        const uint32_t run_max = (uint32_t)std::max(64, env_int("PT_STREAM_RUN", 1024));
+        for (band.pix0 = 0; band.pix0 < n_pixels; band.pix0 += band_pix) {
+            band.npix = std::min(band_pix, n_pixels - band.pix0);
+            for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
+                ps.samples = std::min(spass, pr->spp - done);
+                ps.sample_base = pr->sample_offset + done;
+                const uint64_t paths = (uint64_t)ps.samples * band.npix;
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_max, (paths + block - 1) / block);
+                // a wave's run: long enough to keep its lanes on neighbouring pixels, short enough for 16 runs per wave
+                band.run = (uint32_t)std::min<uint64_t>(run_max, std::max<uint64_t>(64, paths / ((uint64_t)grid * (block / 64) * 16) / 64 * 64));
+                PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
+                tm.begin(1);
+#define PT_LAUNCH_STREAM(C, B, K) hipLaunchKernelGGL((k_paths_stream<C, B, K>), dim3(grid), dim3(B), stack_bytes, stream, ctx->sc, ps, band, ctx->d_prad, ctx->d_ticket, ctx->d_cnt, serve_min)
+#define PT_LAUNCH_STREAM_B(C, K) do { if (block == 256) PT_LAUNCH_STREAM(C, 256, K); else PT_LAUNCH_STREAM(C, 512, K); } while (0)
+                if (count) { if (cones) PT_LAUNCH_STREAM_B(true, true); else PT_LAUNCH_STREAM_B(true, false); }
+                else { if (cones) PT_LAUNCH_STREAM_B(false, true); else PT_LAUNCH_STREAM_B(false, false); }
+#undef PT_LAUNCH_STREAM_B
+#undef PT_LAUNCH_STREAM
+                tm.end();
+                hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, band.npix)), dim3(PT_BLOCK), 0, stream, ps, (const float *)ctx->d_prad, d_rgb_sum, (const uint32_t *)nullptr, ctx->d_cnt,
+                                   band.pix0, band.npix);
+            }
+        }
+        PT_HIP(ctx, hipGetLastError());
+        PT_HIP(ctx, hipEventRecord(ev1, stream));
+        if (stats) {
+            memset(stats, 0, sizeof *stats);
+            Counters h;
+            PT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_cnt, sizeof h, hipMemcpyDeviceToHost, stream));
+            PT_HIP(ctx, hipStreamSynchronize(stream));
+            stats->rays = h.rays;
+            stats->primary_rays = (uint64_t)pr->spp * n_pixels;
+            stats->box_tests = h.box_tests;
+            stats->prim_tests = h.prim_tests;
+            stats->exact_fallbacks = h.exact_fallbacks;
+            stats->exact_replays = h.exact_replays;
+            stats->launches_intersect = n_passes;
+            stats->passes = n_passes;
+            float ms = 0.0f;
+            PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+            stats->ms_total = ms;
+            if (tm.on) {
+                double acc = 0;
+                for (size_t k = 0; k < tm.stage.size(); ++k) {
+                    float m = 0.0f;
+                    PT_HIP(ctx, hipEventElapsedTime(&m, ctx->events[2 + 2 * k], ctx->events[3 + 2 * k]));
+                    acc += m;
+                }
+                stats->ms_paths = acc;
+            }
+        }
+        return PT_OK;
+    }
+
     // Paths per slice: 32k amortises a slice's ramp-down best, but a frame needs a few slices per resident
     // workgroup to balance (a slice's cost varies several-fold with what its pixels see).
     const uint64_t total_paths = (uint64_t)n_pixels * pr->spp;
@@ -2007,22 +2184,13 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
     sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.ticket = ctx->d_ticket;
-    const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 16)));
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (stream_kernel) {
-            const bool cones = ctx->has_cones;
-#define PT_LAUNCH_REFILL(C, B, K) hipLaunchKernelGGL((k_paths_stream<C, B, K>), dim3(grid), dim3(B), stack_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt, serve_min)
-#define PT_LAUNCH_REFILL_B(C, K) do { if (block == 256) PT_LAUNCH_REFILL(C, 256, K); else PT_LAUNCH_REFILL(C, 512, K); } while (0)
-            if (count) { if (cones) PT_LAUNCH_REFILL_B(true, true); else PT_LAUNCH_REFILL_B(true, false); }
-            else { if (cones) PT_LAUNCH_REFILL_B(false, true); else PT_LAUNCH_REFILL_B(false, false); }
-#undef PT_LAUNCH_REFILL_B
-#undef PT_LAUNCH_REFILL
-        } else if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         else launch_paths<false>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }

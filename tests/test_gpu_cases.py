@@ -313,3 +313,23 @@ def test_large_scene_render_crop(ctx, which):
     frac, rmse = _image_close(got[y0:y0 + h, x0:x0 + w], ref)
     assert frac <= 0.015 and rmse < 5e-3, (which, frac, rmse)
     assert np.isfinite(got).all() and st["exact_fallbacks"] == 0 and st["rays"] > st["primary_rays"]
+
+
+def test_path_through_a_nan_hit_is_answered_by_the_list(ctx):
+    """Sample 4 of pixel (1102, 400) of the 100k-object scene at 4K: its second ray hits a cone at t = NaN, which
+    the reference's comparisons accept (cone.h:117-137 tests `root < t_min || t_max < root`), and the path goes on
+    from a NaN point for the remaining 48 bounces; hittable_list::hit then accepts every object and ends on the
+    last one, until the depth runs out (the sample is black: albedos times zero).  No box can prune such a ray:
+    the list scan answers it (counted in exact_fallbacks)."""
+    b = scenes.mixed_scene()
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    x0, y0, w, h = 1100, 398, 6, 4
+    got, st = ctx.render(3840, 2160, 1, 50, sample_offset=4)
+    ref, _ = osc.render(3840, 2160, 1, 50, sample0=4, region=(x0, y0, w, h))
+    crop = got[y0:y0 + h, x0:x0 + w]
+    assert (ref[2, 2] == 0).all() and (crop[2, 2] == 0).all()
+    frac, rmse = _image_close(crop, ref)
+    assert frac <= 0.05 and rmse < 5e-3, (frac, rmse)
+    assert st["exact_fallbacks"] >= 48 and st["rays"] > st["primary_rays"]
+    assert np.isfinite(got).all()
