@@ -1026,7 +1026,8 @@ struct SliceDev {
     float2 *qC;
     float *rad;   // [grid][cap*3]
     uint32_t cap; // paths per slice = pix_per_slice * samples
-    uint32_t pix_per_slice, n_slices;
+    uint32_t pix_per_slice, n_slices; // the largest slice; slices in the table
+    const uint2 *extents;             // [n_slices] (first pixel, pixels): decreasing sizes towards the end of the frame
     uint32_t *ticket;
 };
 
@@ -1094,8 +1095,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         const uint32_t slice = s_slice;
         mark(0);
         if (slice >= sl.n_slices) break;
-        const uint32_t pix0 = slice * sl.pix_per_slice;
-        const uint32_t npix = min(sl.pix_per_slice, ps.n_pixels - pix0);
+        const uint2 extent = sl.extents[slice]; // first pixel, pixels
+        const uint32_t pix0 = extent.x;
+        const uint32_t npix = extent.y;
         uint32_t in_count = npix * ps.samples;
         uint32_t cur = 0;
         for (int32_t b = 0; b < ps.max_depth && in_count > 0; ++b) {
@@ -1592,6 +1594,9 @@ struct pt_context {
     float2 *d_sC = nullptr;
     float *d_srad = nullptr;
     uint32_t *d_ticket = nullptr;
+    uint2 *d_extents = nullptr; // slice table of the last frame shape
+    size_t cap_extents = 0;
+    uint32_t ext_key[4] = {0, 0, 0, 0}, n_extents = 0;
     // k_paths_stream: finished radiance of one pass, [samples][pixels][3]
     float *d_prad = nullptr;
     size_t cap_prad = 0; // paths
@@ -1660,6 +1665,7 @@ static void free_scene(pt_context *ctx)
 static void free_workspace(pt_context *ctx)
 {
     hipFree(ctx->d_prad); ctx->d_prad = nullptr; ctx->cap_prad = 0;
+    hipFree(ctx->d_extents); ctx->d_extents = nullptr; ctx->cap_extents = 0; ctx->n_extents = 0;
     for (int k = 0; k < 2; ++k) { hipFree(ctx->d_A[k]); hipFree(ctx->d_B[k]); hipFree(ctx->d_C[k]); ctx->d_A[k] = ctx->d_B[k] = nullptr; ctx->d_C[k] = nullptr; }
     hipFree(ctx->d_hits); hipFree(ctx->d_rad); ctx->d_hits = nullptr; ctx->d_rad = nullptr;
     ctx->cap_paths = 0;
@@ -2157,10 +2163,33 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     uint32_t pix = std::max(64u, (target / spass) & ~63u);
     const uint32_t cap = pix * spass;
     if ((uint64_t)cap * 3 >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one slice");
-    const uint32_t n_slices = (n_pixels + pix - 1) / pix;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    // Slices: full-sized ones while plenty of work is left, then sizes falling with what remains (what is
+    // left / resident workgroups, never under a quarter of the full size), so that the workgroups finish the
+    // frame together: a slice costs its workgroup 0.5-4 ms and several-fold more or less with what its pixels see.
+    const uint32_t pix_min = std::max(64u, (pix / (uint32_t)std::max(1, env_int("PT_PATHS_TAPER", 4))) & ~63u);
+    if (ctx->ext_key[0] != n_pixels || ctx->ext_key[1] != pix || ctx->ext_key[2] != grid_max || ctx->ext_key[3] != pix_min || !ctx->n_extents) {
+        std::vector<uint2> ext;
+        for (uint32_t at = 0; at < n_pixels;) {
+            const uint32_t left = n_pixels - at;
+            uint32_t take = std::min(pix, std::max(pix_min, (left / grid_max) & ~63u));
+            take = std::min(take, left);
+            ext.push_back(make_uint2(at, take));
+            at += take;
+        }
+        if (ext.size() > ctx->cap_extents) {
+            hipFree(ctx->d_extents);
+            ctx->d_extents = nullptr; ctx->cap_extents = 0;
+            PT_HIP(ctx, hipMalloc(&ctx->d_extents, ext.size() * sizeof(uint2)));
+            ctx->cap_extents = ext.size();
+        }
+        PT_HIP(ctx, hipMemcpy(ctx->d_extents, ext.data(), ext.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        ctx->ext_key[0] = n_pixels; ctx->ext_key[1] = pix; ctx->ext_key[2] = grid_max; ctx->ext_key[3] = pix_min;
+        ctx->n_extents = (uint32_t)ext.size();
+    }
+    const uint32_t n_slices = ctx->n_extents;
     const uint32_t grid = std::min(grid_max, n_slices);
 
-    PT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = (size_t)grid * cap;
     if (need > ctx->cap_slice_paths) {
         hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad);
@@ -2183,7 +2212,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     ps.max_depth = pr->max_depth;
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
-    sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.ticket = ctx->d_ticket;
+    sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.extents = ctx->d_extents; sl.ticket = ctx->d_ticket;
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
