@@ -337,4 +337,111 @@ std::string refit_bvh(const pt_scene_desc &d, BvhBuild &bvh)
     return "";
 }
 
+
+namespace {
+
+struct WideChild {
+    Box box;
+    int32_t ref;
+};
+
+// step 2^(e-127) and origin for one axis of a wide node whose children span [lo, hi]
+void quantisation_grid(float lo, float hi, uint8_t &e_out, float &origin)
+{
+    const double ext = (double)hi - (double)lo;
+    int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+    e = std::max(e, -126);
+    for (;; ++e) {
+        const double s = std::ldexp(1.0, e);
+        const double k = std::floor((double)lo / s);
+        if (std::fabs(k) > 8388608.0 || std::fabs((double)hi / s) > 8388608.0) continue; // origin + q * s must stay exact in fp32
+        if (((double)hi - k * s) / s > 255.0) continue;
+        e_out = (uint8_t)(e + 127);
+        origin = (float)(k * s);
+        return;
+    }
+}
+
+struct WideMaker {
+    const BvhBuild &bvh;
+    WideBuild &out;
+
+    static double area(const Box &b)
+    {
+        const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    }
+    void children_of(int32_t node, std::vector<WideChild> &kids) const
+    {
+        const HostNode &n = bvh.nodes[(size_t)node];
+        for (int c = 0; c < 2; ++c) {
+            if (!(n.b[0][c] < kInf)) continue; // absent
+            WideChild k;
+            for (int a = 0; a < 3; ++a) { k.box.lo[a] = n.b[a][c]; k.box.hi[a] = n.b[a][2 + c]; }
+            k.ref = n.c[c];
+            kids.push_back(k);
+        }
+    }
+    // emits the wide node that stands for binary node `node`; returns its index
+    int32_t emit(int32_t node, uint32_t depth)
+    {
+        out.max_depth = std::max(out.max_depth, depth);
+        std::vector<WideChild> kids;
+        children_of(node, kids);
+        while (kids.size() < 4) { // pull up the inner child with the largest surface
+            int pick = -1;
+            double best = -1.0;
+            for (size_t k = 0; k < kids.size(); ++k)
+                if (kids[k].ref >= 0 && area(kids[k].box) > best) { best = area(kids[k].box); pick = (int)k; }
+            if (pick < 0) break;
+            const int32_t inner = kids[(size_t)pick].ref;
+            kids.erase(kids.begin() + pick);
+            children_of(inner, kids);
+        }
+        const int32_t me = (int32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        WideNode w{};
+        Box u;
+        box_empty(u);
+        for (const WideChild &k : kids) box_grow(u, k.box);
+        float step[3];
+        for (int a = 0; a < 3; ++a) {
+            quantisation_grid(u.lo[a], u.hi[a], w.exp[a], w.origin[a]);
+            step[a] = std::ldexp(1.0f, (int)w.exp[a] - 127);
+        }
+        w.n_children = (uint8_t)kids.size();
+        for (int k = 0; k < 4; ++k) {
+            w.c[k] = kWideAbsent;
+            for (int a = 0; a < 3; ++a) { w.qlo[a][k] = 255; w.qhi[a][k] = 0; }
+        }
+        for (size_t k = 0; k < kids.size(); ++k) {
+            for (int a = 0; a < 3; ++a) {
+                int ql = (int)std::floor(((double)kids[k].box.lo[a] - w.origin[a]) / step[a]);
+                int qh = (int)std::ceil(((double)kids[k].box.hi[a] - w.origin[a]) / step[a]);
+                ql = std::min(std::max(ql, 0), 255);
+                qh = std::min(std::max(qh, 0), 255);
+                // the decoded planes, as the device computes them, must enclose the child's box
+                while (ql > 0 && w.origin[a] + (float)ql * step[a] > kids[k].box.lo[a]) --ql;
+                while (qh < 255 && w.origin[a] + (float)qh * step[a] < kids[k].box.hi[a]) ++qh;
+                w.qlo[a][k] = (uint8_t)ql;
+                w.qhi[a][k] = (uint8_t)qh;
+            }
+        }
+        for (size_t k = 0; k < kids.size(); ++k) w.c[k] = kids[k].ref >= 0 ? emit(kids[k].ref, depth + 1) : kids[k].ref;
+        out.nodes[(size_t)me] = w;
+        return me;
+    }
+};
+
+} // namespace
+
+void make_wide(const BvhBuild &bvh, WideBuild &out)
+{
+    out.nodes.clear();
+    out.nodes.reserve(bvh.nodes.size() / 2 + 2);
+    out.max_depth = 0;
+    WideMaker m{bvh, out};
+    m.emit(0, 1);
+}
+
 } // namespace pt

@@ -67,6 +67,31 @@ struct BvhBuild {
 // extent (the part of the origin-to-object distance that a cone growing with t cannot see).
 bool prim_box(uint8_t type, const float *param, float kappa, float extra, Box &out);
 
+// Four-wide node with quantised child boxes, 64 B: what k_paths_stream fetches per traversal step.  Made from
+// the binary tree by pulling grandchildren up (the child with the largest surface first), so it answers
+// exactly what the binary tree answers.  A child's box on axis a is
+//   [origin[a] + qlo * 2^(exp[a] - 127),  origin[a] + qhi * 2^(exp[a] - 127)],
+// rounded outwards; origin[a] is a multiple of the axis' step small enough (|origin| / step <= 2^23) that
+// origin + q * step is exact in fp32, so the decoded planes are exactly these numbers on the device too.
+struct WideNode {
+    float origin[3];
+    uint8_t exp[3], n_children;
+    uint8_t qlo[3][4]; // [axis][child]
+    uint8_t qhi[3][4];
+    int32_t c[4];      // as in the binary node: >= 0 a WideNode, < 0 ~((first << 3) | (count - 1)); unused slots hold kWideAbsent
+    uint32_t pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+constexpr int32_t kWideAbsent = INT32_MIN + 1;
+
+struct WideBuild {
+    std::vector<WideNode> nodes; // nodes[0] is the root
+    uint32_t max_depth = 0;      // wide nodes on the longest root-to-leaf path
+};
+
+// The four-wide form of a binary tree (after a build or a refit).  O(N).
+void make_wide(const BvhBuild &bvh, WideBuild &out);
+
 // Binned SAH (16 bins per axis), leaves of at most leaf_max objects.  Returns "" or an error text.
 std::string build_bvh(const pt_scene_desc &desc, uint32_t leaf_max, BvhBuild &out);
 
