@@ -232,6 +232,53 @@ PT_DI void box_test2(const float2 &nx, const float2 &ny, const float2 &nz, const
     h1 = tn1 <= tf1 + b.eps;
 }
 
+// A second bound for rays that run almost parallel to a coordinate plane.  On an axis where the cone widens
+// faster than the ray advances (w = kappa |d| / |d_x| > 1) the planes the ray "meets last" give no upper
+// bound on t (make_box_ray leaves that slot open) but a LOWER one: a box lying behind the ray on that axis
+// is only reached once the cone has grown out to it, t >= (far plane distance) / (1 - w) (and never for w < 1,
+// which make_box_ray also leaves open from 0.99 on).  Without it such a
+// ray is let into every box behind it on the axis -- a quarter of a large scene for a ray along a coordinate
+// axis, 300k-500k steps for one ray among the 1M spheres.  Few rays are that steep (two axes: about one in a
+// million), so the constants are worked out where they are needed instead of being carried by every ray.
+struct SteepBounds {
+    float ax, cx, ay, cy, az, cz; // t >= plane * a + c per axis (a = 0, c = -3e38: no such bound)
+    float eps;                    // absolute rounding allowance of these distances
+};
+PT_DI void steep_axis(float o, float d, float kd, float &a2, float &c2, float &cmax)
+{
+    const float tiny = 8.6736174e-19f;
+    const float dd = fabsf(d) < tiny ? copysignf(tiny, d) : d; // as box_ray_axis
+    const float inv = __builtin_amdgcn_rcpf(dd);
+    const float w = kd * fabsf(inv);
+    a2 = 0.0f;
+    c2 = -3.0e38f;
+    if (!(w < 0.99f)) { // the axes whose far slot make_box_ray leaves open
+        // 1 / (w - 1), rounded down (the bound may only come out too low).  Up to w = 1.25 the factor is at least 4
+        // and ill-conditioned: 4 serves there, and below w = 1, where a box behind the ray is never reached at all.
+        const float h = (w > 1.25f ? __builtin_amdgcn_rcpf(w - 1.0f) : 4.0f) * 0.999995f;
+        a2 = -(inv * h);
+        c2 = (o * inv) * h;
+        cmax = fmaxf(cmax, fabsf(c2));
+    }
+}
+PT_DI SteepBounds make_steep_bounds(const Ray &r, float kappa)
+{
+    SteepBounds s;
+    const float kd = kappa * __builtin_amdgcn_sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z) * 1.000001f; // as make_box_ray
+    float cmax = 0.0f;
+    steep_axis(r.o.x, r.d.x, kd, s.ax, s.cx, cmax);
+    steep_axis(r.o.y, r.d.y, kd, s.ay, s.cy, cmax);
+    steep_axis(r.o.z, r.d.z, kd, s.az, s.cz, cmax);
+    s.eps = cmax * (1.0f / 4194304.0f);
+    return s;
+}
+// true if the box with these far planes (the ones the ray meets last per axis) is out of the cone's reach before t_far
+PT_DI bool steep_rejects(const SteepBounds &s, float pfx, float pfy, float pfz, float t_far, float eps)
+{
+    const float lx = __builtin_fmaf(pfx, s.ax, s.cx), ly = __builtin_fmaf(pfy, s.ay, s.cy), lz = __builtin_fmaf(pfz, s.az, s.cz);
+    return fmaxf(fmaxf(lx, ly), lz) > t_far + eps + s.eps; // (a NaN from an infinite plane times zero never rejects)
+}
+
 // Nearest hit through the BVH, with the list scan's semantics:
 //  * an object's root is accepted under the reference's own test !(root < t_min || t_max < root)
 //    with t_max = the running nearest t, so equal t is accepted (hittable_list.h:93-95), and
@@ -258,6 +305,7 @@ PT_DI void planes_of_record(const float4 &a, const float4 &b, const float4 &c, c
 }
 
 struct GlobalSrc {
+    static constexpr bool in_lds = false;
     const BvhNode *nodes;
     const PrimRec *prims;
     pt::ConeParams cone;
@@ -275,6 +323,7 @@ struct GlobalSrc {
     }
 };
 struct LdsSrc {
+    static constexpr bool in_lds = true;
     const float4 *nodes; // 4 planes of n_nodes
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
@@ -485,7 +534,12 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
                             ProfLanes *prof = nullptr)
 {
-    const BoxRay br = make_box_ray(r, ray_kappa(src.cone, r.o));
+    const float kappa = ray_kappa(src.cone, r.o);
+    const BoxRay br = make_box_ray(r, kappa);
+    // An axis whose far slot is open (rare).  Only followed up for scenes traversed from HBM, where such a ray
+    // otherwise walks a large part of the tree; on the LDS-resident scenes (at most 1000 objects) the test costs
+    // the kernel more registers than those rays cost it time (C2: 20.9 -> 22.1 ms with it).
+    const bool steep = !Src::in_lds && (br.afx == 0.0f || br.afy == 0.0f || br.afz == 0.0f);
 
     float best_t = t_max;
     uint32_t best_slot = PT_NO_PRIM, best_id = 0;
@@ -510,6 +564,13 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
             box_test2(nx, ny, nz, fx, fy, fz, br, t_min, best_t, h0, h1, tn0, tn1);
             if (COUNT) n_box += 2;
             if (kProf && prof) prof->tick(0);
+            if (!Src::in_lds && steep) { // the bound the open far slot leaves out (see SteepBounds)
+                const SteepBounds sb = make_steep_bounds(r, kappa);
+                const float tf0 = fminf(fminf(__builtin_fmaf(fx.x, br.afx, br.cfx), __builtin_fmaf(fy.x, br.afy, br.cfy)), fminf(__builtin_fmaf(fz.x, br.afz, br.cfz), best_t));
+                const float tf1 = fminf(fminf(__builtin_fmaf(fx.y, br.afx, br.cfx), __builtin_fmaf(fy.y, br.afy, br.cfy)), fminf(__builtin_fmaf(fz.y, br.afz, br.cfz), best_t));
+                if (steep_rejects(sb, fx.x, fy.x, fz.x, tf0, br.eps)) h0 = false;
+                if (steep_rejects(sb, fx.y, fy.y, fz.y, tf1, br.eps)) h1 = false;
+            }
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
                 int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
@@ -1312,53 +1373,6 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
 #ifndef PT_STREAM_WAVES
 #define PT_STREAM_WAVES 5
 #endif
-// A second bound for rays that run almost parallel to a coordinate plane.  On an axis where the cone widens
-// faster than the ray advances (w = kappa |d| / |d_x| > 1) the planes the ray "meets last" give no upper
-// bound on t (make_box_ray leaves that slot open) but a LOWER one: a box lying behind the ray on that axis
-// is only reached once the cone has grown out to it, t >= (far plane distance) / (1 - w) (and never for w < 1,
-// which make_box_ray also leaves open from 0.99 on).  Without it such a
-// ray is let into every box behind it on the axis -- a quarter of a large scene for a ray along a coordinate
-// axis, 300k-500k steps for one ray among the 1M spheres.  Few rays are that steep (two axes: about one in a
-// million), so the constants are worked out where they are needed instead of being carried by every ray.
-struct SteepBounds {
-    float ax, cx, ay, cy, az, cz; // t >= plane * a + c per axis (a = 0, c = -3e38: no such bound)
-    float eps;                    // absolute rounding allowance of these distances
-};
-PT_DI void steep_axis(float o, float d, float kd, float &a2, float &c2, float &cmax)
-{
-    const float tiny = 8.6736174e-19f;
-    const float dd = fabsf(d) < tiny ? copysignf(tiny, d) : d; // as box_ray_axis
-    const float inv = __builtin_amdgcn_rcpf(dd);
-    const float w = kd * fabsf(inv);
-    a2 = 0.0f;
-    c2 = -3.0e38f;
-    if (!(w < 0.99f)) { // the axes whose far slot make_box_ray leaves open
-        // 1 / (w - 1), rounded down (the bound may only come out too low).  Up to w = 1.25 the factor is at least 4
-        // and ill-conditioned: 4 serves there, and below w = 1, where a box behind the ray is never reached at all.
-        const float h = (w > 1.25f ? __builtin_amdgcn_rcpf(w - 1.0f) : 4.0f) * 0.999995f;
-        a2 = -(inv * h);
-        c2 = (o * inv) * h;
-        cmax = fmaxf(cmax, fabsf(c2));
-    }
-}
-PT_DI SteepBounds make_steep_bounds(const Ray &r, float kappa)
-{
-    SteepBounds s;
-    const float kd = kappa * __builtin_amdgcn_sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z) * 1.000001f; // as make_box_ray
-    float cmax = 0.0f;
-    steep_axis(r.o.x, r.d.x, kd, s.ax, s.cx, cmax);
-    steep_axis(r.o.y, r.d.y, kd, s.ay, s.cy, cmax);
-    steep_axis(r.o.z, r.d.z, kd, s.az, s.cz, cmax);
-    s.eps = cmax * (1.0f / 4194304.0f);
-    return s;
-}
-// true if the box with these far planes (the ones the ray meets last per axis) is out of the cone's reach before t_far
-PT_DI bool steep_rejects(const SteepBounds &s, float pfx, float pfy, float pfz, float t_far, float eps)
-{
-    const float lx = __builtin_fmaf(pfx, s.ax, s.cx), ly = __builtin_fmaf(pfy, s.ay, s.cy), lz = __builtin_fmaf(pfz, s.az, s.cz);
-    return fmaxf(fmaxf(lx, ly), lz) > t_far + eps + s.eps; // (a NaN from an infinite plane times zero never rejects)
-}
-
 // One pass of k_paths_stream: `samples` samples (PassDev) of the pixels [pix0, pix0 + npix).
 struct BandDev {
     uint32_t pix0, npix;
