@@ -169,6 +169,14 @@ pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32
 pt_status pt_bvh_refit_host(const pt_scene_desc *before, const pt_scene_desc *after, uint32_t *n_nodes, uint32_t *max_depth,
                             void *nodes_out, uint32_t *order_out);
 
+/* The four-wide form of that tree, which renders of scenes too large for on-chip memory traverse (host-side tests,
+ * no GPU needed; nothing in the reference: its scan is linear).  64-byte records: float origin[3]; uint8 exp[3],
+ * n_children; uint8 qlo[3][4], qhi[3][4] ([axis][child]); int32 child[4] (>= 0 a record, < 0 a leaf reference as in
+ * the binary nodes, INT32_MIN + 1 unused); 8 bytes of padding.  A child's box on axis a is
+ * origin[a] + q * 2^(exp[a] - 127) for q = qlo, qhi, exactly, and encloses the binary tree's box of that child.
+ * Pass nodes_out = NULL to size the buffer; *max_depth counts records on the longest path. */
+pt_status pt_bvh_wide_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out);
+
 /* How wide a cone the traversal gives its rays in this scene (host-side tests, no GPU needed).  The
  * reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) accept hits up to
  * about 2^-10 of the origin-to-object distance outside the exact surfaces; the tree culls against a

@@ -24,7 +24,7 @@ FLT_MAX = float(np.finfo(np.float32).max)
 EXPORTS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload", "pt_scene_update",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
-    "pt_bvh_build_host", "pt_bvh_refit_host", "pt_scene_ray_cone", "pt_version",
+    "pt_bvh_build_host", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
         L.pt_camera_look_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(PtCamera)]
         L.pt_bvh_build_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.pt_scene_ray_cone.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRayCone)]
+        L.pt_bvh_wide_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
         L.pt_bvh_refit_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -208,6 +209,24 @@ def bvh_refit_host(before, after):
     if st != PT_OK:
         raise PtError(st, "pt_bvh_refit_host")
     return nodes, order, depth.value
+
+
+WIDE_NODE_DTYPE = np.dtype([("origin", "<f4", (3,)), ("exp", "u1", (3,)), ("n_children", "u1"), ("qlo", "u1", (3, 4)), ("qhi", "u1", (3, 4)),
+                            ("c", "<i4", (4,)), ("pad", "<u4", (2,))])
+WIDE_ABSENT = -(2 ** 31) + 1
+
+
+def bvh_wide_host(desc):
+    """The four-wide, quantised form of the tree (pt_bvh_wide_host); returns (records, max_depth)."""
+    n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
+    st = lib().pt_bvh_wide_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), None)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_wide_host")
+    nodes = np.zeros(n_nodes.value, dtype=WIDE_NODE_DTYPE)
+    st = lib().pt_bvh_wide_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), nodes.ctypes.data)
+    if st != PT_OK:
+        raise PtError(st, "pt_bvh_wide_host")
+    return nodes, depth.value
 
 
 def scene_ray_cone(desc):

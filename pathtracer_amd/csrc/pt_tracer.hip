@@ -1941,6 +1941,21 @@ extern "C" pt_status pt_bvh_refit_host(const pt_scene_desc *before, const pt_sce
     return PT_OK;
 }
 
+extern "C" pt_status pt_bvh_wide_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out)
+{
+    std::string e = validate_desc(desc);
+    if (!e.empty()) return PT_ERR_INVALID;
+    pt::BvhBuild b;
+    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
+    if (!e.empty()) return PT_ERR_INVALID;
+    pt::WideBuild w;
+    pt::make_wide(b, w);
+    if (n_nodes) *n_nodes = (uint32_t)w.nodes.size();
+    if (max_depth) *max_depth = w.max_depth;
+    if (nodes_out) memcpy(nodes_out, w.nodes.data(), w.nodes.size() * sizeof(pt::WideNode));
+    return PT_OK;
+}
+
 extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *out)
 {
     if (!out) return PT_ERR_INVALID;

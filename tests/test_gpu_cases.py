@@ -333,3 +333,42 @@ def test_path_through_a_nan_hit_is_answered_by_the_list(ctx):
     assert frac <= 0.05 and rmse < 5e-3, (frac, rmse)
     assert st["exact_fallbacks"] >= 48 and st["rays"] > st["primary_rays"]
     assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("which", ["spheres", "mixed"])
+def test_views_along_a_coordinate_axis(ctx, which, monkeypatch):
+    """A camera looking straight down the z axis through a 0.05 degree lens: every primary ray runs almost parallel
+    to two coordinate planes, where the slab test's cone widens faster than the ray advances and the planes the
+    ray meets last bound t from below instead of from above.  The image must be the oracle's, and the same bit for
+    bit from every traversal: binary and four-wide nodes, with and without path queues."""
+    if which == "spheres":
+        src = scenes.sphere_slab_scene(n=3000, seed=5)
+        a = src.arrays()
+        a["prim_param"][1:, 0] *= np.float32(0.05)  # a 20 x 50 x 20 column of spheres
+        a["prim_param"][1:, 2] *= np.float32(0.05)
+        cam = ((0.0, 25.0, 300.0), (0.0, 25.0, 0.0), (0, 1, 0), 0.05, 1.0, 0.0, 300.0)
+    else:
+        src = scenes.mixed_scene(n=3000, extent=30.0)
+        a = src.arrays()
+        cam = ((15.0, 15.0, 200.0), (15.0, 15.0, 0.0), (0, 1, 0), 0.05, 1.0, 0.0, 200.0)
+    b = scenes.ArrayScene(a, src.background, cam)
+    w, h, spp, depth = 48, 48, 2, 8
+    ctx.upload(b.desc())
+    base, st = ctx.render(w, h, spp, depth)
+    ref, rays = util.oracle_scene(b).render(w, h, spp, depth)
+    frac, rmse = _image_close(base, ref)
+    assert frac <= 0.01 and rmse < 5e-3 and st["rays"] == rays, (frac, rmse, st["rays"], rays)
+    assert (ref.sum(axis=2) > 0).mean() > 0.5
+    monkeypatch.setenv("PT_PATHS_STREAM", "0")  # the queue-based kernel on the binary tree in HBM
+    img, s2 = ctx.render(w, h, spp, depth)
+    monkeypatch.delenv("PT_PATHS_STREAM")
+    assert s2["rays"] == st["rays"] and np.array_equal(img.view(np.uint32), base.view(np.uint32))
+    monkeypatch.setenv("PT_STREAM_WIDE", "1" if which == "mixed" else "0")  # the node form that is not this scene's default
+    ctx.upload(b.desc())
+    img, s2 = ctx.render(w, h, spp, depth)
+    assert s2["rays"] == st["rays"] and np.array_equal(img.view(np.uint32), base.view(np.uint32))
+    o = np.tile(np.array(cam[0], dtype=np.float32), (6, 1))  # and the same through pt_trace_rays
+    d = np.array([[0, 0, -1], [1e-4, 0, -1], [0, -1e-4, -1], [1e-3, 1e-3, -1], [-1e-5, 2e-4, -1], [0, 1e-6, -1]], dtype=np.float32)
+    want = util.oracle_scene(b).trace(o, d)
+    for mode in (api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
+        assert not util.hits_equal(ctx.trace(o, d, mode=mode), want).any()

@@ -247,3 +247,49 @@ def test_leaf_boxes_carry_the_objects_share_of_the_cone():
                 assert (pad_lo >= need).all() and (pad_hi >= need).all()
                 found += 1
     assert found == len(pp)
+
+
+@pytest.mark.parametrize("make", [scenes.default_scene, scenes.cornell_scene, scenes.random_spheres_scene,
+                                  lambda: scenes.mixed_scene(n=3000, extent=30.0), lambda: scenes.sphere_slab_scene(n=5000)])
+def test_wide_tree_holds_the_binary_tree(make):
+    """The four-wide quantised records: the same leaves as the binary tree, each once; every leaf's box (as the
+    binary tree holds it) lies inside the decoded box of every record entry above it; the decoding grid is exact
+    in fp32 (origin a multiple of the step, |origin| / step <= 2^23)."""
+    b = make()
+    d = b.desc()
+    nodes, order, _ = api.bvh_build_host(d)
+    wide, depth = api.bvh_wide_host(d)
+    leaf_box = {}
+    for nd in nodes:
+        for k in range(2):
+            if nd["c"][k] < 0 and np.isfinite(nd["b"][:, k]).all():
+                leaf_box[int(nd["c"][k])] = (nd["b"][:, k].astype(np.float64), nd["b"][:, 2 + k].astype(np.float64))
+    seen = set()
+
+    def walk(i, above, level):
+        w = wide[i]
+        step = np.ldexp(1.0, w["exp"].astype(int) - 127)
+        k0 = w["origin"].astype(np.float64) / step
+        assert (k0 == np.round(k0)).all() and (np.abs(k0) <= 2 ** 23).all()
+        n = int(w["n_children"])
+        assert 1 <= n <= 4 and (w["c"][n:] == api.WIDE_ABSENT).all() and (w["c"][:n] != api.WIDE_ABSENT).all()
+        deepest = level
+        for k in range(n):
+            lo = w["origin"] + w["qlo"][:, k].astype(np.float32) * step.astype(np.float32)  # as the device decodes it
+            hi = w["origin"] + w["qhi"][:, k].astype(np.float32) * step.astype(np.float32)
+            assert (lo.astype(np.float64) == k0 * step + w["qlo"][:, k] * step).all()      # ... exactly
+            ref = int(w["c"][k])
+            chain = above + [(lo.astype(np.float64), hi.astype(np.float64))]
+            if ref >= 0:
+                deepest = max(deepest, walk(ref, chain, level + 1))
+            else:
+                assert ref not in seen
+                seen.add(ref)
+                blo, bhi = leaf_box[ref]
+                for alo, ahi in chain:
+                    assert (alo <= blo).all() and (bhi <= ahi).all()
+        return deepest
+
+    assert walk(0, [], 1) == depth
+    assert seen == set(leaf_box)
+    assert len(wide) <= len(nodes)
