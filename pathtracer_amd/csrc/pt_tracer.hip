@@ -1383,7 +1383,8 @@ struct BandDev {
 template <bool COUNT, int BLOCK, bool CONES, bool WIDE>
 __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
                                                                            uint32_t *__restrict__ ticket, Counters *cnt,
-                                                                           uint32_t serve_min /* lanes waiting for shading or a new path before they are served */, unsigned long long *dbg = nullptr /* diagnostic build only */, uint32_t dbg_waves = 0)
+                                                                           uint32_t serve_min /* lanes waiting for shading or a new path before they are served */, uint32_t phase_bias /* 0: node and leaf steps in every iteration */,
+                                                                           unsigned long long *dbg = nullptr /* diagnostic build only */, uint32_t dbg_waves = 0)
 {
     extern __shared__ float4 s_mem[];
     uint32_t *const stack = reinterpret_cast<uint32_t *>(s_mem) + threadIdx.x;
@@ -1546,7 +1547,15 @@ __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVE
                 if (__ballot(lid != PT_NO_PRIM) == 0ull) break; // no path left in this wave, none to take
                 continue;
             }
-            if (node != PT_TRAVERSAL_DONE) {
+            // One kind of step per iteration, the one more lanes are waiting for: the two kinds share no code, and
+            // run in the same iteration each would execute with the lanes of the other masked off.
+            bool my_turn = true;
+            if (phase_bias) {
+                const uint32_t n_inner = (uint32_t)__popcll(__ballot(node >= 0)), n_leaf = (uint32_t)__popcll(__ballot(node < 0 && node != PT_TRAVERSAL_DONE));
+                const bool inner_turn = n_inner * phase_bias >= n_leaf * 4u; // phase_bias = 4: plain majority
+                my_turn = (node >= 0) == inner_turn;
+            }
+            if (node != PT_TRAVERSAL_DONE && my_turn) {
                 if (kProf) dbg_steps++;
                 const bool inner = node >= 0;
                 const uint32_t ref = (uint32_t)~node; // leaf: (first object << 3) | (objects left - 1)
@@ -1770,13 +1779,13 @@ static int env_int(const char *name, int dflt)
 }
 
 // Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
-// lose 10-20 %); scenes traversed from HBM pay per record fetched, and two objects come with every 64-byte
-// fetch: 8 per leaf is 5-15 % faster than 4 there (100k objects 129 -> 122 ms, 1M spheres 367 -> 312 ms).
+// lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 3 (1M spheres
+// 2.41 / 2.57 / 2.76 / 2.85 / 2.94 Grays/s for 8 / 6 / 4 / 3 / 2, 100k mixed objects 1.77 / 1.98 / 2.10 / 2.25 / 2.07).
 // PT_LEAF_MAX overrides (tuning).
 static uint32_t leaf_max_for(const pt_scene_desc *desc)
 {
     if (const char *v = getenv("PT_LEAF_MAX")) return (uint32_t)atoi(v);
-    return desc->n_prims > 1000u ? 8u : (uint32_t)PT_LEAF_MAX;
+    return desc->n_prims > 1000u ? 3u : (uint32_t)PT_LEAF_MAX;
 }
 
 static pt_status fail(pt_context *ctx, pt_status st, const std::string &msg)
@@ -2292,8 +2301,11 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
         ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
         ps.max_depth = pr->max_depth;
-        const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 16)));
+        const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 32)));
         const bool cones = ctx->has_cones;
+        // one kind of step per iteration where the leaf code is long (cones): 100k mixed objects 1.86 -> 2.10 Grays/s;
+        // both kinds in every iteration otherwise (1M spheres 2.76 against 2.66)
+        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", cones ? 4 : 0));
         unsigned long long *dbg = nullptr;
         const size_t dbg_waves = (size_t)grid_max * (block / 64);
         if (kProf) { // diagnostic build: per-wave start / end clocks and step counts, reported after the call
@@ -2315,7 +2327,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
                 band.run = (uint32_t)std::min<uint64_t>(run_max, std::max<uint64_t>(64, paths / ((uint64_t)grid * (block / 64) * 16) / 64 * 64));
                 PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
                 tm.begin(1);
-#define PT_LAUNCH_STREAM(C, B, K, W) hipLaunchKernelGGL((k_paths_stream<C, B, K, W>), dim3(grid), dim3(B), stream_stack_bytes, stream, ctx->sc, ps, band, ctx->d_prad, ctx->d_ticket, ctx->d_cnt, serve_min, dbg, (uint32_t)dbg_waves)
+#define PT_LAUNCH_STREAM(C, B, K, W) hipLaunchKernelGGL((k_paths_stream<C, B, K, W>), dim3(grid), dim3(B), stream_stack_bytes, stream, ctx->sc, ps, band, ctx->d_prad, ctx->d_ticket, ctx->d_cnt, serve_min, phase_bias, dbg, (uint32_t)dbg_waves)
 #define PT_LAUNCH_STREAM_W(C, B, K) do { if (wide) PT_LAUNCH_STREAM(C, B, K, true); else PT_LAUNCH_STREAM(C, B, K, false); } while (0)
 #define PT_LAUNCH_STREAM_B(C, K) do { if (block == 256) PT_LAUNCH_STREAM_W(C, 256, K); else PT_LAUNCH_STREAM_W(C, 512, K); } while (0)
                 if (count) { if (cones) PT_LAUNCH_STREAM_B(true, true); else PT_LAUNCH_STREAM_B(true, false); }
