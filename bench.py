@@ -167,8 +167,8 @@ def main():
                      "peak_tflops": VALU_PEAK_TFLOPS, "peak_kind": "fp32 vector, non-packed", "flops_per_ray": fpr},
             "note": "algorithmic bytes (32B+32P+100 per ray) over event-timed k_paths launches; for cache-resident scenes the "
                     "figure is a rate of useful bytes, not HBM traffic (see `traffic`, from rocprofv3 PMC passes); on the "
-                    "LDS-resident scenes the kernel is VALU-issue-bound (profiles/r01_pmc_c2.json), on the large ones bound "
-                    "by scattered 64-byte L2 misses",
+                    "LDS-resident scenes the kernel is VALU-issue-bound (profiles/r01_pmc_c2.json), and so is k_paths_stream on the "
+                    "large ones (profiles/r01_pmc_c5_8spp.json)",
         }
         if cnt is not None and cnt["rays"]:
             roofline["measured_B"] = cnt["box_tests"] / cnt["rays"]
