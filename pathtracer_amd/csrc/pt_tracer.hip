@@ -366,6 +366,9 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
     uint32_t ids[PT_SCAN_MAX], slots[PT_SCAN_MAX];
     int n = 0;
     overflow = false;
+    const bool steep = br.afx == 0.0f || br.afy == 0.0f || br.afz == 0.0f;
+    SteepBounds sb = {0.0f, -3.0e38f, 0.0f, -3.0e38f, 0.0f, -3.0e38f, 0.0f};
+    if (steep) sb = make_steep_bounds(r, ray_kappa(src.cone, r.o));
     uint32_t sp = 0;
     int32_t cur = 0;
     for (;;) {
@@ -376,6 +379,12 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
             float tn0, tn1;
             bool h0, h1;
             box_test2(nx, ny, nz, fx, fy, fz, br, t_min, t_max, h0, h1, tn0, tn1);
+            if (steep) { // the bound the open far slot leaves out (see SteepBounds)
+                const float tf0 = fminf(fminf(__builtin_fmaf(fx.x, br.afx, br.cfx), __builtin_fmaf(fy.x, br.afy, br.cfy)), fminf(__builtin_fmaf(fz.x, br.afz, br.cfz), t_max));
+                const float tf1 = fminf(fminf(__builtin_fmaf(fx.y, br.afx, br.cfx), __builtin_fmaf(fy.y, br.afy, br.cfy)), fminf(__builtin_fmaf(fz.y, br.afz, br.cfz), t_max));
+                if (steep_rejects(sb, fx.x, fy.x, fz.x, tf0, br.eps)) h0 = false;
+                if (steep_rejects(sb, fx.y, fy.y, fz.y, tf1, br.eps)) h1 = false;
+            }
             if (h0 && h1) {
                 if (sp < stack_cap) stack[(sp++) * STRIDE] = (uint32_t)c1;
                 else overflow = true;
