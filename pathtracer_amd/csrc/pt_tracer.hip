@@ -1663,12 +1663,39 @@ __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVE
                     q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
                     q.meta = __float_as_uint(w1.z);
                     q.id = __float_as_uint(w1.w);
-                    object_test<CONES>(q, first, r, t_min, t_max, nh);
-                    if (left > 1) {
-                        q.p[0] = w2.x; q.p[1] = w2.y; q.p[2] = w2.z; q.p[3] = w2.w; q.p[4] = w3.x; q.p[5] = w3.y;
-                        q.meta = __float_as_uint(w3.z);
-                        q.id = __float_as_uint(w3.w);
-                        object_test<CONES>(q, first + 1u, r, t_min, t_max, nh);
+                    if (CONES) { // (this variant has no registers to spare for the split below: 100k mixed objects 3 % slower with it)
+                        object_test<CONES>(q, first, r, t_min, t_max, nh);
+                        if (left > 1) {
+                            q.p[0] = w2.x; q.p[1] = w2.y; q.p[2] = w2.z; q.p[3] = w2.w; q.p[4] = w3.x; q.p[5] = w3.y;
+                            q.meta = __float_as_uint(w3.z);
+                            q.id = __float_as_uint(w3.w);
+                            object_test<CONES>(q, first + 1u, r, t_min, t_max, nh);
+                        }
+                    } else {
+                        PrimRec q2;
+                        q2.p[0] = w2.x; q2.p[1] = w2.y; q2.p[2] = w2.z; q2.p[3] = w2.w; q2.p[4] = w3.x; q2.p[5] = w3.y;
+                        q2.meta = __float_as_uint(w3.z);
+                        q2.id = __float_as_uint(w3.w);
+                        // Spheres first, in two halves (sphere.h:85-101): the discriminants of both, then the roots -- a
+                        // correctly rounded sqrt and divides, the expensive part -- once for every lane that has a candidate,
+                        // and once more only where a lane has two.  (The answer does not depend on the order in which the
+                        // objects of a leaf are tried: equal t goes to the later list entry either way.)
+                        const bool sph1 = (q.meta & 7u) == PT_SPHERE, sph2 = left > 1 && (q2.meta & 7u) == PT_SPHERE;
+                        float hb1 = 0.0f, disc1 = 0.0f, hb2 = 0.0f, disc2 = 0.0f;
+                        const bool cand1 = sph1 && sphere_discriminant(q, r, hb1, disc1);
+                        const bool cand2 = sph2 && sphere_discriminant(q2, r, hb2, disc2);
+                        if (cand1 && cand2) {
+                            float t = 0.0f;
+                            const bool h = sphere_roots(r, hb1, disc1, t_min, nh.best_t, t);
+                            nh.take(h, t, first, q.id);
+                        }
+                        if (cand1 || cand2) {
+                            float t = 0.0f;
+                            const bool h = sphere_roots(r, cand2 ? hb2 : hb1, cand2 ? disc2 : disc1, t_min, nh.best_t, t);
+                            nh.take(h, t, cand2 ? first + 1u : first, cand2 ? q2.id : q.id);
+                        }
+                        if (!sph1) object_test<CONES>(q, first, r, t_min, t_max, nh);
+                        if (left > 1 && !sph2) object_test<CONES>(q2, first + 1u, r, t_min, t_max, nh);
                     }
                     if (COUNT) np += left > 1 ? 2u : 1u;
                     if (nh.best_t != nh.best_t) { // a hit at t = NaN was accepted: from here on the scan's answer is a matter of list order
@@ -2251,6 +2278,20 @@ static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool ld
 #undef PT_LAUNCH_PATHS
 }
 
+// The k_paths_stream instance for a launch shape.
+static const void *stream_kernel_for(bool count, int block, bool cones, bool wide)
+{
+#define PT_STREAM_PTR(C, B, K, W) reinterpret_cast<const void *>(&k_paths_stream<C, B, K, W>)
+#define PT_STREAM_W(C, B, K) (wide ? PT_STREAM_PTR(C, B, K, true) : PT_STREAM_PTR(C, B, K, false))
+#define PT_STREAM_K(C, B) (cones ? PT_STREAM_W(C, B, true) : PT_STREAM_W(C, B, false))
+#define PT_STREAM_B(C) (block == 256 ? PT_STREAM_K(C, 256) : PT_STREAM_K(C, 512))
+    return count ? PT_STREAM_B(true) : PT_STREAM_B(false);
+#undef PT_STREAM_B
+#undef PT_STREAM_K
+#undef PT_STREAM_W
+#undef PT_STREAM_PTR
+}
+
 // The persistent-workgroup pipeline (k_paths).  Tuning knobs are read from the environment once:
 // PT_PATHS_BLOCK (256|512), PT_PATHS_LDS (0|1), PT_PATHS_PER_CU, PT_PATHS_SLICE (paths per slice), PT_PATHS_SORT (0|1).
 static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
@@ -2276,8 +2317,13 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     if (per_cu <= 0) {
         const size_t static_lds = 64 + (sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
         const size_t lds_used = (stream_kernel ? stream_stack_bytes : lds_bytes) + static_lds;
-        const int waves_per_simd = stream_kernel ? (ctx->has_cones ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVES) : 6; // the kernels' register budgets
+        const int waves_per_simd = stream_kernel ? PT_STREAM_WAVES : 6; // the kernels' register budgets
         per_cu = std::min<int>(waves_per_simd * 4 * 64 / block, (int)((160 * 1024) / std::max<size_t>(lds_used, 1)));
+        if (stream_kernel) { // what the runtime will really keep resident (its cone variants take more registers than the budget)
+            int fit = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, stream_kernel_for(count, block, ctx->has_cones, wide), block, stream_stack_bytes) == hipSuccess && fit > 0)
+                per_cu = std::min(per_cu, fit);
+        }
         per_cu = std::max(per_cu, 1);
     }
     const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
@@ -2336,14 +2382,15 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
                 band.run = (uint32_t)std::min<uint64_t>(run_max, std::max<uint64_t>(64, paths / ((uint64_t)grid * (block / 64) * 16) / 64 * 64));
                 PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
                 tm.begin(1);
-#define PT_LAUNCH_STREAM(C, B, K, W) hipLaunchKernelGGL((k_paths_stream<C, B, K, W>), dim3(grid), dim3(B), stream_stack_bytes, stream, ctx->sc, ps, band, ctx->d_prad, ctx->d_ticket, ctx->d_cnt, serve_min, phase_bias, dbg, (uint32_t)dbg_waves)
-#define PT_LAUNCH_STREAM_W(C, B, K) do { if (wide) PT_LAUNCH_STREAM(C, B, K, true); else PT_LAUNCH_STREAM(C, B, K, false); } while (0)
-#define PT_LAUNCH_STREAM_B(C, K) do { if (block == 256) PT_LAUNCH_STREAM_W(C, 256, K); else PT_LAUNCH_STREAM_W(C, 512, K); } while (0)
-                if (count) { if (cones) PT_LAUNCH_STREAM_B(true, true); else PT_LAUNCH_STREAM_B(true, false); }
-                else { if (cones) PT_LAUNCH_STREAM_B(false, true); else PT_LAUNCH_STREAM_B(false, false); }
-#undef PT_LAUNCH_STREAM_B
-#undef PT_LAUNCH_STREAM_W
-#undef PT_LAUNCH_STREAM
+                {
+                    SceneDev a_sc = ctx->sc;
+                    float *a_rad = ctx->d_prad;
+                    uint32_t *a_ticket = ctx->d_ticket;
+                    Counters *a_cnt = ctx->d_cnt;
+                    uint32_t a_serve = serve_min, a_phase = phase_bias, a_dbgw = (uint32_t)dbg_waves;
+                    void *args[] = {&a_sc, &ps, &band, &a_rad, &a_ticket, &a_cnt, &a_serve, &a_phase, &dbg, &a_dbgw};
+                    PT_HIP(ctx, hipLaunchKernel(stream_kernel_for(count, block, cones, wide), dim3(grid), dim3(block), args, stream_stack_bytes, stream));
+                }
                 tm.end();
                 hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, band.npix)), dim3(PT_BLOCK), 0, stream, ps, (const float *)ctx->d_prad, d_rgb_sum, (const uint32_t *)nullptr, ctx->d_cnt,
                                    band.pix0, band.npix);
