@@ -44,14 +44,15 @@ def flops_per_ray(B, P):
     return 24.0 * B + 30.0 * P + 60.0
 
 
-def cpu_baseline(scene_builder, depth, seed):
+def cpu_baseline(scene_builder, depth, seed, W, H, SPP):
     """The CPU oracle (a port of the reference's per-object hit / linear scan / scatter code) on a
     bounded sample of the same workload: same scene, depth and stream, reduced image and spp."""
     from oracle import pt_oracle as O
     from tests import util
 
     osc = util.oracle_scene(scene_builder)
-    w, h, spp = 960, 540, 8
+    shrink = min(1.0, 960.0 / W)  # C2: a quarter of the pixels at the workload's own spp, about 10 s on 16 cores
+    w, h, spp = int(W * shrink), int(H * shrink), min(SPP, 64)
     n_prims = len(scene_builder.arrays()["prim_type"])
     if n_prims > 5000:  # the scan is O(objects) per ray: shrink the sample for the big scenes
         w, h, spp = 96, 54, 1
@@ -183,7 +184,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(builder, depth, args.seed)
+            out["cpu_baseline"] = cpu_baseline(builder, depth, args.seed, W, H, spp)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
