@@ -29,6 +29,6 @@ derived = {
 }
 notes = ("FETCH_SIZE/WRITE_SIZE are in KiB on this ROCm (x1024 here); gfx950 counts 128-B read requests as 64 B, hence 2 x FETCH_SIZE; "
          "Infinity-Cache hits are included. GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* are in units of "
-         "4 cycles. VALU instructions do not all issue in 4 cycles on gfx950 (tests/mb/valu_tput.hip), so the x4 ratio is an index, not a utilisation.")
+         "4 cycles. VALU instructions do not all issue in 4 cycles on gfx950 (tools/mb/valu_tput.hip), so the x4 ratio is an index, not a utilisation.")
 json.dump({"workload": desc, "kernel": kern, "counters_per_launch": c, "derived": derived, "notes": notes}, open(out, "w"), indent=1)
 print(json.dumps(derived, indent=1))
