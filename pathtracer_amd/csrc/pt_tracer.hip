@@ -514,6 +514,90 @@ PT_DI void object_test(const PrimRec &q, uint32_t slot, const Ray &r, float t_mi
     nh.take(h, t, slot, q.id);
 }
 
+// The same test for a wave whose lanes hold objects of different kinds (scenes with cones are mixed scenes).  Run
+// through object_test() such a wave executes the code of every kind present, one after the other: ~230 vector
+// instructions when all six are.  Here the three quadrics share one code path and the three rects another:
+//  * sphere.h:85-101, cylinder.h:96-123 and cone.h:101-129 are the same computation -- oc, a, half_b, c,
+//    discriminant, the roots (-half_b -+ sqrtd) / a tried in that order, then a clip of the hit's y -- with
+//    different inputs: the cylinder and the cone drop the y components of oc and d (the reference zeroes them
+//    and still goes through dot() and length_squared(), and x*x + 0*0 + z*z rounds as x*x + z*z does), the cone
+//    adds its tangens terms, the sphere has no clip (bounds -inf, +inf).  Every product and sum below is the one
+//    the reference's expression for that kind performs, in its order.
+//  * aarect.h:348-355, :364-371, :380-387 differ only in which components they read.
+PT_DI bool quadric_roots(const PrimRec &q, uint32_t type, const Ray &r, ConeRoots &cr)
+{
+    const bool is_sphere = type == PT_SPHERE, is_cone = type == PT_CONE;
+    const v3 center = V(q.p[0], q.p[1], q.p[2]);
+    v3 oc = vsub(r.o, center);
+    v3 dd = r.d;
+    oc.y = is_sphere ? oc.y : 0.0f;
+    dd.y = is_sphere ? dd.y : 0.0f;
+    float a = vlen2(dd);
+    float half_b = vdot(oc, dd);
+    const float height = q.p[3]; // (the sphere's radius sits here; its clip bounds below do not use it)
+    const float radius = is_sphere ? q.p[3] : q.p[4];
+    float k = radius * radius;
+    if (is_cone) {
+        const float tangens = q.p[5];
+        const float D = height - r.o.y + center.y;
+        a = a - tangens * r.d.y * r.d.y;
+        half_b = half_b + tangens * r.d.y * D;
+        k = tangens * D * D;
+    }
+    const float c = vlen2(oc) - k;
+    const float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return false;
+    const float sqrtd = sqrtf(discriminant);
+    cr.a = a;
+    cr.r1 = (-half_b - sqrtd) / a;
+    cr.r2 = (-half_b + sqrtd) / a;
+    cr.cy = is_sphere ? -__builtin_inff() : center.y;
+    cr.cyh = is_sphere ? __builtin_inff() : center.y + height;
+    cr.oy = r.o.y;
+    cr.dy = r.d.y;
+    return true;
+}
+PT_DI void object_test_fused(const PrimRec &q, uint32_t slot, const Ray &r, float t_min, float t_max, Nearest &nh)
+{
+    const uint32_t type = q.meta & 7u;
+    float t = 0.0f;
+    bool h = false;
+    if (type - (uint32_t)PT_XY_RECT < 3u) {
+        const bool xy = type == PT_XY_RECT, yz = type == PT_YZ_RECT;
+        const float o_k = xy ? r.o.z : (yz ? r.o.x : r.o.y), d_k = xy ? r.d.z : (yz ? r.d.x : r.d.y); // the axis the rect is normal to
+        const float o_0 = yz ? r.o.y : r.o.x, d_0 = yz ? r.d.y : r.d.x;
+        const float o_1 = xy ? r.o.y : r.o.z, d_1 = xy ? r.d.y : r.d.z;
+        t = (q.p[4] - o_k) / d_k;
+        if (!(t < t_min || t > nh.best_t)) {
+            const float c0 = o_0 + t * d_0;
+            const float c1 = o_1 + t * d_1;
+            h = !(c0 < q.p[0] || c0 > q.p[1] || c1 < q.p[2] || c1 > q.p[3]);
+        }
+    } else {
+        ConeRoots cr;
+        if (quadric_roots(q, type, r, cr)) {
+            if (!(cr.a < 0.0f)) { // spheres and cylinders always (their a is a sum of squares, or NaN)
+                h = hit_cone_ordered(cr, t_min, nh.best_t, t);
+            } else { // as in object_test()
+                if (!(cr.r1 < t_min || nh.best_t < cr.r1) && cone_clip_ok(cr, cr.r1)) {
+                    h = true;
+                    t = cr.r1;
+                }
+                if (!(cr.r2 < t_min || nh.best_t < cr.r2) && !(cr.r1 < t_min) && cone_clip_ok(cr, cr.r2)) {
+                    if (t_max < cr.r1) {
+                        h = true;
+                        t = cr.r2;
+                    } else {
+                        if (nh.n_pend == 0) { nh.pend_slot = slot; nh.pend_id = q.id; nh.pend_r2 = cr.r2; nh.pend_r1 = cr.r1; }
+                        nh.n_pend++;
+                    }
+                }
+            }
+        }
+    }
+    nh.take(h, t, slot, q.id);
+}
+
 // After the traversal: decides the parked cone candidate where the traversal's knowledge suffices,
 // otherwise asks for the exact replay.
 template <bool CONES>
@@ -1663,13 +1747,13 @@ __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVE
                     q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
                     q.meta = __float_as_uint(w1.z);
                     q.id = __float_as_uint(w1.w);
-                    if (CONES) { // (this variant has no registers to spare for the split below: 100k mixed objects 3 % slower with it)
-                        object_test<CONES>(q, first, r, t_min, t_max, nh);
+                    if (CONES) { // mixed scenes: one code path per family of objects (and no registers to spare for the split below: 3 % slower with it)
+                        object_test_fused(q, first, r, t_min, t_max, nh);
                         if (left > 1) {
                             q.p[0] = w2.x; q.p[1] = w2.y; q.p[2] = w2.z; q.p[3] = w2.w; q.p[4] = w3.x; q.p[5] = w3.y;
                             q.meta = __float_as_uint(w3.z);
                             q.id = __float_as_uint(w3.w);
-                            object_test<CONES>(q, first + 1u, r, t_min, t_max, nh);
+                            object_test_fused(q, first + 1u, r, t_min, t_max, nh);
                         }
                     } else {
                         PrimRec q2;
@@ -2303,8 +2387,13 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const SceneDev &sc = ctx->sc;
     const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32;
     int block = env_int("PT_PATHS_BLOCK", 0);
-    if (block != 256 && block != 512) // LDS-resident scenes: 512 (one scene copy per 8 waves); HBM scenes: 256 measured best
-        block = want_lds && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024 ? 512 : 256;
+    if (block != 256 && block != 512) {
+        // LDS-resident scenes: 512 (one scene copy per 8 waves).  Scenes traversed from HBM: 256 measured best without cones;
+        // with cones 512, the shape at which the compiler gets k_paths_stream's cone variant into 128 registers (4 waves per
+        // SIMD instead of the 3 its 132 registers at 256 allow: 100k mixed objects 2.40 -> 2.85 Grays/s)
+        const bool fits_lds = want_lds && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024;
+        block = fits_lds || ctx->has_cones ? 512 : 256;
+    }
     const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
     bool lds = want_lds && scene_bytes + stack_bytes <= 64 * 1024;
     const size_t lds_bytes = stack_bytes + (lds ? scene_bytes : 0);
