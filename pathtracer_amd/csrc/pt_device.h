@@ -13,7 +13,7 @@
 
 #define PT_FLT_MAX 3.402823466e+38f
 #define PT_MAX_TRIES 64    // bound on the reference's unbounded rejection loops (cuda_functions.h:16-18,67-69)
-#define PT_LEAF_MAX 4      // objects per BVH leaf for scenes traversed from LDS (8 for larger ones)
+#define PT_LEAF_MAX 4      // objects per BVH leaf for scenes traversed from LDS (1 for larger ones)
 #define PT_NO_PRIM 0xFFFFFFFFu
 
 // ---------------------------------------------------------------------------------------------

@@ -1899,13 +1899,14 @@ static int env_int(const char *name, int dflt)
 }
 
 // Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
-// lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 3 (1M spheres
-// 2.41 / 2.57 / 2.76 / 2.85 / 2.94 Grays/s for 8 / 6 / 4 / 3 / 2, 100k mixed objects 1.77 / 1.98 / 2.10 / 2.25 / 2.07).
-// PT_LEAF_MAX overrides (tuning).
+// lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 1.  A leaf step
+// costs a wave the object code of every kind of object its lanes hold, once per position in the leaf that any lane
+// still has an object at; a node visit costs a fifth of that.  (1M spheres 3.04 / 3.20 / 3.27 Grays/s for 3 / 2 / 1,
+// 100k mixed objects 2.73 / 2.88 / 3.25 / 3.46 for 4 / 3 / 2 / 1.)  PT_LEAF_MAX overrides (tuning).
 static uint32_t leaf_max_for(const pt_scene_desc *desc)
 {
     if (const char *v = getenv("PT_LEAF_MAX")) return (uint32_t)atoi(v);
-    return desc->n_prims > 1000u ? 3u : (uint32_t)PT_LEAF_MAX;
+    return desc->n_prims > 1000u ? 1u : (uint32_t)PT_LEAF_MAX;
 }
 
 static pt_status fail(pt_context *ctx, pt_status st, const std::string &msg)
@@ -2447,9 +2448,10 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.max_depth = pr->max_depth;
         const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 32)));
         const bool cones = ctx->has_cones;
-        // one kind of step per iteration where the leaf code is long (cones): 100k mixed objects 1.86 -> 2.10 Grays/s;
+        // one kind of step per iteration where the leaf code is long (cones), leaf steps as soon as a third of the
+        // traversing lanes wait for one: 100k mixed objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for 0 / 2 / 3 / 4 / 6;
         // both kinds in every iteration otherwise (1M spheres 2.76 against 2.66)
-        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", cones ? 4 : 0));
+        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", cones ? 2 : 0));
         unsigned long long *dbg = nullptr;
         const size_t dbg_waves = (size_t)grid_max * (block / 64);
         if (kProf) { // diagnostic build: per-wave start / end clocks and step counts, reported after the call
