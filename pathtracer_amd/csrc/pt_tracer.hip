@@ -2448,10 +2448,11 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.max_depth = pr->max_depth;
         const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 32)));
         const bool cones = ctx->has_cones;
-        // one kind of step per iteration where the leaf code is long (cones), leaf steps as soon as a third of the
-        // traversing lanes wait for one: 100k mixed objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for 0 / 2 / 3 / 4 / 6;
-        // both kinds in every iteration otherwise (1M spheres 2.76 against 2.66)
-        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", cones ? 2 : 0));
+        // One kind of step per iteration (the two kinds share no code: run in the same iteration each executes with the
+        // lanes of the other masked off), leaf steps as soon as a third of the traversing lanes wait for one: 100k mixed
+        // objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for PT_STREAM_PHASE 0 (both kinds every iteration) / 2 / 3 / 4 / 6,
+        // 1M spheres 3.29 / 3.39 / 3.41 / 3.32 / 3.25 for 0 / 1 / 2 / 3 / 4.
+        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", 2));
         unsigned long long *dbg = nullptr;
         const size_t dbg_waves = (size_t)grid_max * (block / 64);
         if (kProf) { // diagnostic build: per-wave start / end clocks and step counts, reported after the call
@@ -2461,7 +2462,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         uint32_t n_passes = 0;
         BandDev band;
         band.tile = tile;
-        const uint32_t run_max = (uint32_t)std::max(64, env_int("PT_STREAM_RUN", 1024));
+        // runs of at most 256 paths: 1M spheres 3.41 -> 3.50 Grays/s, 100k mixed objects 3.56 -> 3.73 against 1024 (64 and 128 tie with 256)
+        const uint32_t run_max = (uint32_t)std::max(64, env_int("PT_STREAM_RUN", 256));
         for (band.pix0 = 0; band.pix0 < n_pixels; band.pix0 += band_pix) {
             band.npix = std::min(band_pix, n_pixels - band.pix0);
             for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
