@@ -53,7 +53,7 @@ def test_golden_images(ctx, name):
 # ------------------------------------------------------------------------------------------------
 # the library's pipelines and kernel variants walk the same paths: bit-identical images
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,w,h,spp,depth", [("random_spheres", 192, 108, 4, 50), ("mixed_1k", 96, 54, 3, 8), ("cornell", 64, 64, 4, 5)])
+@pytest.mark.parametrize("name,w,h,spp,depth", [("random_spheres", 192, 108, 4, 50), ("mixed_1k", 96, 54, 6, 12), ("cornell", 64, 64, 4, 5)])
 def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
     ctx.upload(SCENES[name]().desc())
     base, st = ctx.render(w, h, spp, depth)
@@ -72,6 +72,8 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
                 # workgroup sizes, and the queue-based slice kernel
                 {"hbm": "1", "PT_PATHS_STREAM_MIN": "1"}, {"hbm": "1", "PT_PATHS_STREAM_MIN": "64"},
                 {"hbm": "1", "PT_PATHS_BLOCK": "512"}, {"hbm": "1", "PT_PATHS_STREAM": "0"},
+                # node and leaf steps in every iteration / by plain majority; short runs of paths per wave
+                {"hbm": "1", "PT_STREAM_PHASE": "0"}, {"hbm": "1", "PT_STREAM_PHASE": "4"}, {"hbm": "1", "PT_STREAM_RUN": "64"},
                 {"PT_PATHS_STREAM": "1"}):
         env = dict(env)
         flags = api.RENDER_NO_LDS_SCENE if env.pop("hbm", None) else 0
@@ -82,6 +84,22 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
             monkeypatch.delenv(k)
         assert s2["rays"] == st["rays"], env
         assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), env
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth", [("mixed_1k", 96, 54, 4, 12), ("random_spheres", 96, 54, 2, 50)])
+def test_tree_shape_does_not_change_the_image(ctx, name, w, h, spp, depth, monkeypatch):
+    """The answer is the list scan's whatever the tree looks like: leaves of 1 to 8 objects, traversed from LDS by
+    k_paths and from HBM by k_paths_stream (binary or four-wide nodes), give bit-identical images."""
+    ctx.upload(SCENES[name]().desc())
+    base, st = ctx.render(w, h, spp, depth)
+    for leaf in ("1", "2", "3", "8"):
+        monkeypatch.setenv("PT_LEAF_MAX", leaf)
+        ctx.upload(SCENES[name]().desc())
+        monkeypatch.delenv("PT_LEAF_MAX")
+        for flags in (0, api.RENDER_NO_LDS_SCENE):
+            img, s2 = ctx.render(w, h, spp, depth, flags=flags)
+            assert s2["rays"] == st["rays"], (leaf, flags)
+            assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), (leaf, flags)
 
 
 def test_render_is_deterministic_and_seeded(ctx):
