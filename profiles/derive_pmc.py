@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns one collect_pmc.sh run (gpurun_out/pmc/summary.json + the bench line in sq.log) into the per-launch
-counter file kept under profiles/: counters of the dominant kernel and the ratios DESIGN.md quotes.
+counter file kept under profiles/: counters of the dominant kernel and the ratios derived from them.
 Usage: derive_pmc.py <pmc dir> <out.json> "<workload description>" """
 import json, os, sys
 
