@@ -60,10 +60,23 @@ def cpu_baseline(scene_builder, depth, seed, W, H, SPP):
     t0 = time.time()
     _, rays = osc.render(w, h, spp, depth, seed=seed, threads=threads)
     dt = time.time() - t0
-    return {
+    out = {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": "%dx%d %dspp depth%d of the same scene, linear scan as in the reference, %d rays in %.2f s" % (w, h, spp, depth, rays, dt),
     }
+    # Beside it, the same walk with nearest hits found through the library's host-built tree on the CPU: the reference has
+    # no hierarchy (its scan is O(objects) per ray), so this is the figure to hold the GPU's against if the algorithmic
+    # O(N) -> O(log N) gain is not to be credited to the hardware.  Timing only, not a parity reference.
+    nodes, order, _ = api.bvh_build_host(scene_builder.desc())
+    bw, bh, bspp = (W // 2, H // 2, 1) if n_prims > 5000 else (W, H, min(SPP, 64))
+    t0 = time.time()
+    _, brays = osc.render_bvh(nodes, order, bw, bh, bspp, depth, seed=seed, threads=threads)
+    bdt = time.time() - t0
+    out["bvh"] = {
+        "value": brays / bdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port with a tree (not the reference's algorithm)",
+        "sample": "%dx%d %dspp depth%d of the same scene, stack traversal of the library's two-wide tree, %d rays in %.2f s" % (bw, bh, bspp, depth, brays, bdt),
+    }
+    return out
 
 
 def main():

@@ -336,6 +336,88 @@ int orc_hit_list(const orc_scene *s, const float o[3], const float d[3], float t
     return hit_list(s, vload(o), vload(d), t_min, t_max, rec);
 }
 
+/* ------------------------------------------------- tree traversal on the CPU (baseline timing only) */
+/* NOT part of the reference (it scans its list, hittable_list.h:87-101) and not a parity checker: a plain
+ * stack traversal of the tree the GPU library builds (64-byte nodes: per axis lo of child 0, lo of child 1,
+ * hi of child 0, hi of child 1; two child references, negative = leaf ~((first << 3) | (count - 1)) into
+ * `order`), so that a CPU figure with the same O(log N) algorithm stands beside the linear-scan one.  Boxes
+ * are culled by exact geometry, slightly padded: the few hits the reference's fp32 arithmetic reports outside
+ * the exact surfaces (which the GPU traversal keeps) may be lost here, and a cone's list-order dependence is
+ * ignored.  Equal t goes to the later list index. */
+typedef struct orc_accel {
+    const float *nodes; /* 16 words per node */
+    const uint32_t *order;
+    uint32_t n_nodes;
+} orc_accel;
+static const orc_accel *g_accel; /* set by orc_render_bvh for the duration of its call */
+
+static int hit_tree(const orc_scene *s, const orc_accel *acc, v3 o, v3 d, float t_min, float t_max, orc_hit *rec)
+{
+    int32_t stack[128];
+    int sp = 0, have = 0;
+    float best = t_max;
+    uint32_t nan_flag = 0;
+    orc_hit temp;
+    float inv[3];
+    for (int a = 0; a < 3; ++a) inv[a] = 1.0f / d.e[a];
+    memset(&temp, 0, sizeof temp);
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float *nd = acc->nodes + (size_t)cur * 16;
+            const int32_t *ch = (const int32_t *)(nd + 12);
+            int hit[2];
+            float tn[2];
+            for (int k = 0; k < 2; ++k) {
+                float t0 = t_min, t1 = best;
+                for (int a = 0; a < 3; ++a) {
+                    float x0 = (nd[4 * a + k] - o.e[a]) * inv[a], x1 = (nd[4 * a + 2 + k] - o.e[a]) * inv[a];
+                    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+                    x0 -= fabsf(x0) * 1e-5f;
+                    x1 += fabsf(x1) * 1e-5f;
+                    if (x0 > t0) t0 = x0;
+                    if (x1 < t1) t1 = x1;
+                }
+                hit[k] = t0 <= t1;
+                tn[k] = t0;
+            }
+            if (hit[0] && hit[1]) {
+                int nearc = tn[1] < tn[0];
+                if (sp < 128) stack[sp++] = ch[!nearc];
+                cur = ch[nearc];
+                continue;
+            }
+            if (hit[0]) { cur = ch[0]; continue; }
+            if (hit[1]) { cur = ch[1]; continue; }
+        } else {
+            uint32_t ref = (uint32_t)~cur, first = ref >> 3, count = (ref & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                uint32_t i = acc->order[first + k];
+                temp.nan_flag = 0;
+                if (hit_prim(s, i, o, d, t_min, best, &temp) && (!have || temp.t < best || i > rec->prim)) {
+                    have = 1;
+                    best = temp.t;
+                    if (temp.t != temp.t) nan_flag |= 1;
+                    nan_flag |= temp.nan_flag;
+                    *rec = temp;
+                    rec->prim = i;
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    rec->nan_flag = nan_flag;
+    return have;
+}
+
+/* what ray_color queries: the reference's list scan, or the tree while orc_render_bvh runs */
+static int hit_world(const orc_scene *s, v3 o, v3 d, float t_min, float t_max, orc_hit *rec)
+{
+    const orc_accel *acc = g_accel;
+    return acc ? hit_tree(s, acc, o, d, t_min, t_max, rec) : hit_list(s, o, d, t_min, t_max, rec);
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
@@ -459,8 +541,10 @@ static v3 ray_color(const orc_scene *s, v3 o, v3 d, int depth, rng_t *g, uint32_
     if (depth <= 0) return V(0, 0, 0);
     ++*rays;
     memset(&rec, 0, sizeof rec);
-    int h = hit_list(s, o, d, 0.001f, FLT_MAX /* commons.h:11 */, &rec);
-    if (getenv("ORC_PRINT_PATH")) /* diagnostic: the path's rays and hits, one line per bounce */
+    int h = hit_world(s, o, d, 0.001f, FLT_MAX /* commons.h:11 */, &rec);
+    static int print_path = -1; /* diagnostic (ORC_PRINT_PATH): the path's rays and hits, one line per bounce; read once */
+    if (print_path < 0) print_path = getenv("ORC_PRINT_PATH") != NULL;
+    if (print_path)
         fprintf(stderr, "[orc] bounce %u o %.9g %.9g %.9g d %.9g %.9g %.9g hit %d prim %u type %d t %.9g n %.9g %.9g %.9g front %d\n", bounce - 1,
                 o.e[0], o.e[1], o.e[2], d.e[0], d.e[1], d.e[2], h, h ? rec.prim : 0u, h ? (int)s->prim_type[rec.prim] : -1, rec.t, rec.n[0],
                 rec.n[1], rec.n[2], (int)rec.front);
@@ -519,6 +603,17 @@ uint64_t orc_render(const orc_scene *s, int width, int height, uint32_t sample0,
                     uint64_t seed, float *rgb_sum, int threads)
 {
     return orc_render_region(s, width, height, 0, 0, width, height, sample0, n_samples, depth, seed, rgb_sum, threads);
+}
+
+/* orc_render with nearest-hit queries answered through a tree (see hit_tree): a timing baseline, not the reference. */
+uint64_t orc_render_bvh(const orc_scene *s, const float *nodes, uint32_t n_nodes, const uint32_t *order, int width, int height,
+                        uint32_t sample0, uint32_t n_samples, int depth, uint64_t seed, float *rgb_sum, int threads)
+{
+    orc_accel acc = {nodes, order, n_nodes};
+    g_accel = &acc;
+    uint64_t rays = orc_render_region(s, width, height, 0, 0, width, height, sample0, n_samples, depth, seed, rgb_sum, threads);
+    g_accel = NULL;
+    return rays;
 }
 
 /* commons.h:58-62 */

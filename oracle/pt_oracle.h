@@ -102,6 +102,13 @@ uint64_t orc_render_region(const orc_scene *s, int width, int height, int x0, in
                            uint32_t sample0, uint32_t n_samples, int depth, uint64_t seed, float *rgb_sum,
                            int threads);
 
+/* NOT the reference and not a parity checker: orc_render with its nearest-hit queries answered by a stack traversal
+ * of a two-wide tree (the GPU library's host-side build: 64-byte nodes, leaf slots mapped to list indices by `order`)
+ * instead of the list scan, so that bench.py can put a CPU figure with the same O(log N) algorithm beside the
+ * linear-scan one.  Not reentrant. */
+uint64_t orc_render_bvh(const orc_scene *s, const float *nodes, uint32_t n_nodes, const uint32_t *order, int width, int height,
+                        uint32_t sample0, uint32_t n_samples, int depth, uint64_t seed, float *rgb_sum, int threads);
+
 /* main.cu:95-98 then :194-205: mean, sqrt gamma, 8-bit quantise, rows top-down from j = H-1. */
 void orc_finalize(const float *rgb_sum, int width, int height, uint32_t spp, float *rgb_gamma, uint8_t *rgb8);
 

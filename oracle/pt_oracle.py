@@ -53,6 +53,7 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_render.restype = C.c_uint64
         L.orc_render_region.restype = C.c_uint64
+        L.orc_render_bvh.restype = C.c_uint64
         L.orc_u32_to_uniform.restype = C.c_float
         L.orc_u32_to_uniform.argtypes = [C.c_uint32]
         L.orc_num_threads.restype = C.c_int
@@ -141,6 +142,20 @@ class Scene:
             C.byref(self.c), C.c_int(width), C.c_int(height), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h),
             C.c_uint32(sample0), C.c_uint32(spp), C.c_int(depth), C.c_uint64(seed), C.c_void_p(out.ctypes.data),
             C.c_int(threads),
+        )
+        return out, int(rays)
+
+
+    def render_bvh(self, nodes, order, width, height, spp, depth, seed=1984, sample0=0, threads=0):
+        """Timing baseline only: the same walk with nearest hits found through a tree (nodes: the 64-byte records of
+        the GPU library's host-side build, order: leaf slot -> list index).  Not the reference's algorithm."""
+        nodes = np.ascontiguousarray(nodes)
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        rays = lib().orc_render_bvh(
+            C.byref(self.c), C.c_void_p(nodes.ctypes.data), C.c_uint32(len(nodes)), C.c_void_p(order.ctypes.data),
+            C.c_int(width), C.c_int(height), C.c_uint32(sample0), C.c_uint32(spp), C.c_int(depth), C.c_uint64(seed),
+            C.c_void_p(out.ctypes.data), C.c_int(threads),
         )
         return out, int(rays)
 

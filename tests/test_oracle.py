@@ -255,3 +255,18 @@ def test_orbit_of_shards_equals_whole():
     c, rc = osc.render(64, 36, 2, 5, sample0=2)
     assert ra + rc == r
     assert np.allclose(a.astype(np.float64) + c, full, rtol=1e-6, atol=1e-7)
+
+
+def test_tree_traversal_baseline_walks_the_same_paths():
+    """bench.py's second CPU figure (nearest hits through the library's host-built tree instead of the list scan) is a
+    timing baseline, not the reference's algorithm; on a scene of spheres it must still walk the scan's paths."""
+    from pathtracer_amd import api
+
+    b = scenes.random_spheres_scene()
+    osc = util.oracle_scene(b)
+    nodes, order, _ = api.bvh_build_host(b.desc())
+    ref, rays = osc.render(96, 54, 2, 50)
+    got, rays_tree = osc.render_bvh(nodes, order, 96, 54, 2, 50)
+    assert rays_tree == rays
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
