@@ -68,7 +68,7 @@ def cpu_baseline(scene_builder, depth, seed, W, H, SPP):
     # no hierarchy (its scan is O(objects) per ray), so this is the figure to hold the GPU's against if the algorithmic
     # O(N) -> O(log N) gain is not to be credited to the hardware.  Timing only, not a parity reference.
     nodes, order, _ = api.bvh_build_host(scene_builder.desc())
-    bw, bh, bspp = (W // 2, H // 2, 1) if n_prims > 5000 else (W, H, min(SPP, 64))
+    bw, bh, bspp = (W, H, min(SPP, 2)) if n_prims > 5000 else (W, H, min(SPP, 64))
     t0 = time.time()
     _, brays = osc.render_bvh(nodes, order, bw, bh, bspp, depth, seed=seed, threads=threads)
     bdt = time.time() - t0
