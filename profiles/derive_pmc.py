@@ -27,6 +27,9 @@ derived = {
     "wave_cycles_waiting_fraction": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
     "l2_hit_fraction": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
 }
+derived["memory_side_GB_per_s"] = mem / (cycles / 2.4e9) / 1e9  # against 8000 GB/s of HBM3E (Infinity-Cache hits included)
+derived["memory_side_fraction_of_hbm_peak"] = derived["memory_side_GB_per_s"] / 8000.0
+derived["valu_lane_slots_used_fraction"] = derived["valu_instructions_x4_over_simd_cycles"] * derived["lane_utilisation"]  # share of the vector ALUs' lane-cycles doing work
 notes = ("FETCH_SIZE/WRITE_SIZE are in KiB on this ROCm (x1024 here); gfx950 counts 128-B read requests as 64 B, hence 2 x FETCH_SIZE; "
          "Infinity-Cache hits are included. GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* are in units of "
          "4 cycles. VALU instructions do not all issue in 4 cycles on gfx950 (tools/mb/valu_tput.hip), so the x4 ratio is an index, not a utilisation.")
