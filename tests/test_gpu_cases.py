@@ -333,6 +333,27 @@ def test_large_scene_render_crop(ctx, which):
     assert np.isfinite(got).all() and st["exact_fallbacks"] == 0 and st["rays"] > st["primary_rays"]
 
 
+@pytest.mark.parametrize("n", [30_000, 1_000_000])
+def test_wide_and_binary_nodes_agree_bitwise(ctx, n, monkeypatch):
+    """The four-wide quantised tree only prunes: a field of spheres rendered through it (the default for cone-free
+    scenes in HBM) and through the binary tree it was derived from gives the same image, bit for bit, over some
+    million rays; so does a tree with leaves of three objects."""
+    b = scenes.sphere_slab_scene(n=n)
+    w, h, spp = (640, 360, 3) if n < 100_000 else (960, 540, 1)
+    ctx.upload(b.desc())
+    base, st = ctx.render(w, h, spp, 50)
+    assert st["rays"] > 1.5 * w * h * spp and st["exact_fallbacks"] == 0
+    for env in ({"PT_STREAM_WIDE": "0"}, {"PT_LEAF_MAX": "3"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx.upload(b.desc())
+        for k in env:
+            monkeypatch.delenv(k)
+        img, s2 = ctx.render(w, h, spp, 50)
+        assert s2["rays"] == st["rays"], env
+        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), env
+
+
 def test_path_through_a_nan_hit_is_answered_by_the_list(ctx, monkeypatch):
     """Sample 4 of pixel (1102, 400) of the 100k-object scene at 4K: its second ray hits a cone at t = NaN (the
     cone's leading coefficient is exactly 0 for this direction), which the reference's comparisons accept
