@@ -69,10 +69,10 @@ static inline v3 ray_at(v3 o, v3 d, float t) { return vadd(o, vscale(t, d)); }
 static const uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
 static const uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
 
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -85,39 +85,43 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* (0,1] in steps of 2^-24, like curand_uniform's range (main.cu:90) */
 float orc_u32_to_uniform(uint32_t x) { return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f); }
 
-typedef struct { uint32_t pixel, sample, bounce, block, key[2]; } rng_t;
+/* The stream of one (pixel, sample, bounce): the 32-bit words of Philox4x32-7 blocks 0, 1, 2, ... taken in
+ * order, one word per uniform drawn (curand_uniform's role, main.cu:90-91, cuda_functions.h:17,68,
+ * material.h:235).  `word` counts the words drawn since the bounce began. */
+typedef struct { uint32_t pixel, sample, bounce, word, buf[4], key[2]; } rng_t;
 
-static void rng_block(rng_t *g, float u[4])
+static void rng_start(rng_t *g, uint32_t bounce) { g->bounce = bounce; g->word = 0; }
+
+static float rng_uniform(rng_t *g)
 {
-    uint32_t ctr[4] = {g->block, g->bounce, g->sample, g->pixel}, o[4];
-    orc_philox4x32_10(ctr, g->key, o);
-    g->block++;
-    for (int i = 0; i < 4; ++i) u[i] = orc_u32_to_uniform(o[i]);
+    if ((g->word & 3u) == 0) {
+        uint32_t ctr[4] = {g->word >> 2, g->bounce, g->sample, g->pixel};
+        orc_philox4x32(ctr, g->key, ORC_PHILOX_ROUNDS, g->buf);
+    }
+    return orc_u32_to_uniform(g->buf[g->word++ & 3u]);
 }
 
 #define ORC_MAX_TRIES 64 /* rejection loops are unbounded in the reference; both sides stop here */
 
-/* cuda_functions.h:14-20, one stream block per try, components in block order */
+/* cuda_functions.h:14-20: three uniforms per try, in stream order */
 static v3 random_in_unit_sphere(rng_t *g)
 {
     v3 p;
     int tries = 0;
     do {
-        float u[4];
-        rng_block(g, u);
-        p = vsub(vscale(2.0f, V(u[0], u[1], u[2])), V(1, 1, 1));
+        float u0 = rng_uniform(g), u1 = rng_uniform(g), u2 = rng_uniform(g);
+        p = vsub(vscale(2.0f, V(u0, u1, u2)), V(1, 1, 1));
     } while (vlen2(p) >= 1.0f && ++tries < ORC_MAX_TRIES);
     return p;
 }
-/* cuda_functions.h:65-71 */
+/* cuda_functions.h:65-71: two uniforms per try */
 static v3 random_in_unit_disk(rng_t *g)
 {
     v3 p;
     int tries = 0;
     do {
-        float u[4];
-        rng_block(g, u);
-        p = vsub(vscale(2.0f, V(u[0], u[1], 0)), V(1, 1, 0));
+        float u0 = rng_uniform(g), u1 = rng_uniform(g);
+        p = vsub(vscale(2.0f, V(u0, u1, 0)), V(1, 1, 0));
     } while (vlen2(p) >= 1.0f && ++tries < ORC_MAX_TRIES);
     return p;
 }
@@ -495,7 +499,7 @@ static int scatter_impl(const orc_scene *s, uint32_t mat, v3 ro, v3 rd, const or
         if (!reflect_it) { /* the uniform is drawn only when the first operand of || is false (material.h:235) */
             float xi;
             if (xi_in) xi = *xi_in;
-            else { float u[4]; rng_block(g, u); xi = u[0]; }
+            else xi = rng_uniform(g);
             reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > xi;
         }
         if (reflect_it) direction = vreflect(unit_direction, normal);
@@ -552,8 +556,7 @@ static v3 ray_color(const orc_scene *s, v3 o, v3 d, int depth, rng_t *g, uint32_
     uint32_t mat = s->prim_material[rec.prim];
     v3 attenuation, so, sd;
     v3 emit = emitted(s, mat);
-    g->bounce = bounce;
-    g->block = 0;
+    rng_start(g, bounce);
     if (!scatter_impl(s, mat, o, d, &rec, g, NULL, NULL, &attenuation, &so, &sd)) return emit;
     return vadd(emit, vmul(attenuation, ray_color(s, so, sd, depth - 1, g, bounce + 1, rays)));
 }
@@ -568,13 +571,11 @@ static v3 pixel_sum(const orc_scene *s, int i, int j, int width, int height, uin
     g.key[0] = (uint32_t)seed;
     g.key[1] = (uint32_t)(seed >> 32);
     for (uint32_t k = 0; k < n_samples; ++k) {
-        float u4[4], oo[3], dd[3];
+        float oo[3], dd[3];
         g.sample = sample0 + k;
-        g.bounce = 0;
-        g.block = 0;
-        rng_block(&g, u4);
-        float u = ((float)i + u4[0]) / (float)width;
-        float v = ((float)j + u4[1]) / (float)height;
+        rng_start(&g, 0);
+        float u = ((float)i + rng_uniform(&g)) / (float)width;   /* main.cu:90 */
+        float v = ((float)j + rng_uniform(&g)) / (float)height;  /* main.cu:91 */
         v3 disk = random_in_unit_disk(&g);
         orc_get_ray(s, u, v, disk.e, oo, dd);
         col = vadd(col, ray_color(s, vload(oo), vload(dd), depth, &g, 1, rays));

@@ -18,8 +18,9 @@
  * order, in fp32, compiled with -ffp-contract=off.
  *
  * The random number source is NOT the reference's (cuRAND XORWOW,
- * main.cu:34,87): it is the counter-based Philox4x32-10 stream the GPU path
- * uses, keyed (pixel, sample, bounce, block), so oracle and GPU walk the
+ * main.cu:34,87): it is the counter-based Philox4x32-7 stream the GPU path
+ * uses -- the words of blocks 0, 1, 2, ... of the counter (block, bounce, sample,
+ * pixel) taken in order, one per uniform drawn -- so oracle and GPU walk the
  * same paths.  The sampler algorithms and the draw order are the reference's.
  */
 #ifndef PT_ORACLE_H
@@ -78,8 +79,10 @@ int orc_hit_list(const orc_scene *s, const float o[3], const float d[3], float t
 void orc_trace_batch(const orc_scene *s, const float *o, const float *d, size_t n, float t_min, float t_max,
                      orc_hit *out, int threads);
 
-/* Philox4x32-10 (Salmon et al., SC'11), one block. */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* Philox4x32 (Salmon et al., SC'11), one block of `rounds` rounds (10 is the published default, 7 the
+ * fewest rounds the paper certifies as passing BigCrush and what the renderer's stream uses). */
+#define ORC_PHILOX_ROUNDS 7
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 /* The uniform the renderer draws: (0,1], like curand_uniform. */
 float orc_u32_to_uniform(uint32_t x);
 

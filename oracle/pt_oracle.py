@@ -160,11 +160,14 @@ class Scene:
         return out, int(rays)
 
 
-def philox(ctr, key):
+PHILOX_ROUNDS = 7  # ORC_PHILOX_ROUNDS: what the renderer's stream uses
+
+
+def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(c, k, o)
+    lib().orc_philox4x32(c, k, C.c_int(rounds), o)
     return [int(x) for x in o]
 
 

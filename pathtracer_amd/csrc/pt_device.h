@@ -81,16 +81,20 @@ PT_DI v3 vrefract(v3 uv, v3 n, float etai_over_etat)                            
 PT_DI v3 ray_at(v3 o, v3 d, float t) { return vadd(o, vscale(t, d)); }                 // ray.h:47-49
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based random stream: Philox4x32-10, counter (block, bounce, sample, pixel), key = seed.
-// Stands in for the per-pixel curandState (main.cu:34,87); no state buffer exists.
+// Counter-based random stream: Philox4x32-7, counter (block, bounce, sample, pixel), key = seed.
+// Stands in for the per-pixel curandState (main.cu:34,87); no state buffer exists.  The stream of one
+// (pixel, sample, bounce) is the words of blocks 0, 1, 2, ... in order, one word per uniform drawn
+// (curand_uniform's role): a unit-sphere try takes three, a unit-disk try two, so four sphere tries come
+// out of three blocks.  Seven rounds are the fewest the Philox paper certifies (BigCrush); ten are its default.
 // ---------------------------------------------------------------------------------------------
+#define PT_PHILOX_ROUNDS 7
 struct Rng { uint32_t pixel, sample, bounce, block, k0, k1; };
 
-PT_DI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+PT_DI void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
 {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PT_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 multiply per product (v_mad_u64_u32) instead of separate high and low halves
         const unsigned long long p0 = (unsigned long long)M0 * c0, p1 = (unsigned long long)M1 * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -106,17 +110,15 @@ PT_DI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// the next block of the stream
+PT_DI void rng_words(Rng &g, uint32_t o[4])
+{
+    philox4x32(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
+    g.block++;
+}
+
 // (0,1] in steps of 2^-24: the range of curand_uniform (main.cu:90)
 PT_DI float u32_to_uniform(uint32_t x) { return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f); }
-
-PT_DI void rng_block(Rng &g, float u[4])
-{
-    uint32_t o[4];
-    philox4x32_10(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
-    g.block++;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = u32_to_uniform(o[i]);
-}
 
 // 2u - 1 for the uniform u = ((x >> 8) + 1) * 2^-24 that u32_to_uniform() makes of a random word, as the
 // samplers below need it (cuda_functions.h:17,68: 2.0f * vec3(u..) - vec3(1..)).  The reference rounds once
@@ -128,30 +130,41 @@ PT_DI float u32_to_signed_unit(uint32_t x)
     return __builtin_fmaf((float)(x & 0xFFFFFF00u), 1.0f / 2147483648.0f, 1.0f / 8388608.0f - 1.0f);
 }
 
-// cuda_functions.h:14-20, one block per try
+// cuda_functions.h:14-20.  Try k takes words 3k, 3k+1, 3k+2 of the stream, which must stand at a block
+// boundary on entry (it does: the scatter of a bounce draws nothing before it).
 PT_DI v3 random_in_unit_sphere(Rng &g)
 {
     v3 p;
     int tries = 0;
-    do {
-        uint32_t o[4];
-        philox4x32_10(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
-        g.block++;
-        p = V(u32_to_signed_unit(o[0]), u32_to_signed_unit(o[1]), u32_to_signed_unit(o[2]));
-    } while (vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES);
+    uint32_t a[4], b[4];
+#define PT_SPHERE_TRY(X, Y, Z)                                                                 \
+    p = V(u32_to_signed_unit(X), u32_to_signed_unit(Y), u32_to_signed_unit(Z));                \
+    if (!(vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES)) break;
+    for (;;) {
+        rng_words(g, a);
+        PT_SPHERE_TRY(a[0], a[1], a[2])
+        rng_words(g, b);
+        PT_SPHERE_TRY(a[3], b[0], b[1])
+        rng_words(g, a);
+        PT_SPHERE_TRY(b[2], b[3], a[0])
+        PT_SPHERE_TRY(a[1], a[2], a[3])
+    }
+#undef PT_SPHERE_TRY
     return p;
 }
-// cuda_functions.h:65-71
-PT_DI v3 random_in_unit_disk(Rng &g)
+// cuda_functions.h:65-71 after the two uniforms of the pixel jitter (main.cu:90-91), which are words 0 and 1
+// of the camera stream: `first` is that block, whose words 2 and 3 are the first try.
+PT_DI v3 random_in_unit_disk_after_jitter(Rng &g, const uint32_t first[4])
 {
-    v3 p;
+    v3 p = V(u32_to_signed_unit(first[2]), u32_to_signed_unit(first[3]), 0.0f);
     int tries = 0;
-    do {
+    while (vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES) {
         uint32_t o[4];
-        philox4x32_10(g.block, g.bounce, g.sample, g.pixel, g.k0, g.k1, o);
-        g.block++;
+        rng_words(g, o);
         p = V(u32_to_signed_unit(o[0]), u32_to_signed_unit(o[1]), 0.0f);
-    } while (vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES);
+        if (!(vlen2(p) >= 1.0f && ++tries < PT_MAX_TRIES)) break;
+        p = V(u32_to_signed_unit(o[2]), u32_to_signed_unit(o[3]), 0.0f);
+    }
     return p;
 }
 

@@ -640,6 +640,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     uint32_t n_pend = 0, pend_slot = 0, pend_id = 0;
     float pend_r2 = 0.0f, pend_r1 = 0.0f;
     need_exact = false;
+    bool nan_hit = false;
 
     uint32_t sp = 0;
     int32_t cur = 0; // root
@@ -763,11 +764,15 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
             }
             if (held) release();
         }
+        // A hit at t = NaN was accepted (the reference's comparisons let it through, and from then on what the scan
+        // accepts is a matter of list order: every later entry the ray's line crosses): the list itself answers this ray.
+        if (best_t != best_t) { nan_hit = true; break; }
         if (sp == 0) break;
         cur = (int32_t)stack[(--sp) * STRIDE];
     }
 
-    if (!CONES) {
+    if (nan_hit) need_exact = true;
+    else if (!CONES) {
     } else if (n_pend > 1) need_exact = true;
     else if (n_pend == 1 && !(best_t < pend_r2)) {
         // The parked cone is taken by the scan iff some EARLIER entry was accepted with t < pend_r1.
@@ -784,11 +789,11 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     HitResult res;
     res.t = best_t;
     res.slot = best_slot;
-    if (CONES && need_exact) {
+    if (CONES && need_exact && !nan_hit) {
         res = bvh_exact_scan<STRIDE>(src, stack_cap, r, br, t_min, t_max, stack, need_exact);
         n_replay++;
     }
-    return res; // need_exact still set: more candidates than the replay keeps, the caller scans the list
+    return res; // need_exact still set: a NaN hit, or more candidates than the replay keeps: the caller scans the list
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -939,11 +944,11 @@ PT_DI Ray camera_ray(const DeviceCamera &c, const PassDev &ps, uint32_t pixel, u
     uint32_t j = pixel / ps.width, i = pixel - j * ps.width;
     Rng g;
     g.pixel = pixel; g.sample = sample_abs; g.bounce = 0; g.block = 0; g.k0 = ps.k0; g.k1 = ps.k1;
-    float u4[4];
-    rng_block(g, u4);
-    float u = ((float)i + u4[0]) / (float)ps.width;   // main.cu:90
-    float v = ((float)j + u4[1]) / (float)ps.height;  // main.cu:91
-    v3 disk = random_in_unit_disk(g);
+    uint32_t w4[4];
+    rng_words(g, w4);
+    float u = ((float)i + u32_to_uniform(w4[0])) / (float)ps.width;   // main.cu:90
+    float v = ((float)j + u32_to_uniform(w4[1])) / (float)ps.height;  // main.cu:91
+    v3 disk = random_in_unit_disk_after_jitter(g, w4);
     v3 rd = vscale(c.lens_radius, disk);                                             // camera.h:89
     v3 offset = vadd(vscale(rd.x, V(c.u[0], c.u[1], c.u[2])), vscale(rd.y, V(c.v[0], c.v[1], c.v[2]))); // :90
     v3 origin = V(c.origin[0], c.origin[1], c.origin[2]);
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         uint32_t slot = h.slot;
-        if (CONES && need_exact) {
+        if (need_exact) {
             // resolved on the list-order records; the top bit of the slot says which array it indexes
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             slot = h.slot == PT_NO_PRIM ? PT_NO_PRIM : (h.slot | 0x80000000u);
@@ -1056,9 +1061,9 @@ PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const R
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool reflect_it = refraction_ratio * sin_theta > 1.0f;
         if (!reflect_it) { // the uniform is consumed only when refraction is possible (material.h:235)
-            float u4[4];
-            rng_block(g, u4);
-            reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u4[0];
+            uint32_t w4[4];
+            rng_words(g, w4);
+            reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u32_to_uniform(w4[0]);
         }
         dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
         scattered = true;
@@ -1185,6 +1190,7 @@ struct SliceDev {
     uint32_t pix_per_slice, n_slices; // the largest slice; slices in the table
     const uint2 *extents;             // [n_slices] (first pixel, pixels): decreasing sizes towards the end of the frame
     uint32_t *ticket;
+    uint32_t order; // numbering of a slice's camera rays: 0 pixel-fast (a wave holds one sample of 64 pixels), 1 sample-fast
 };
 
 template <bool COUNT, bool LDS, int BLOCK, bool SORT, bool CONES>
@@ -1236,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         HitResult h;
         if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
         else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
-        if (CONES && need_exact) {
+        if (need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
             nf++;
@@ -1316,14 +1322,16 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                     HitResult h;
                     h.t = 0.0f;
                     h.slot = PT_NO_PRIM;
+                    uint32_t lid0 = i;
                     if (i < in_count) {
                         uint32_t s = i / npix, pl = i - s * npix;
+                        if (sl.order) { pl = i / ps.samples; s = i - pl * ps.samples; lid0 = s * npix + pl; }
                         r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
                         mark(1);
                         h = trace(r);
                     }
                     mark(2);
-                    shade_emit(i < in_count, r, V(1.0f, 1.0f, 1.0f), i, h);
+                    shade_emit(i < in_count, r, V(1.0f, 1.0f, 1.0f), lid0, h);
                     mark(3);
                 } else if (!SORT) {
                     Ray r;
@@ -2614,6 +2622,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
     sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.extents = ctx->d_extents; sl.ticket = ctx->d_ticket;
+    sl.order = (uint32_t)env_int("PT_PATHS_ORDER", 0);
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);

@@ -355,26 +355,37 @@ def test_wide_and_binary_nodes_agree_bitwise(ctx, n, monkeypatch):
 
 
 def test_path_through_a_nan_hit_is_answered_by_the_list(ctx, monkeypatch):
-    """Sample 4 of pixel (1102, 400) of the 100k-object scene at 4K: its second ray hits a cone at t = NaN (the
-    cone's leading coefficient is exactly 0 for this direction), which the reference's comparisons accept
-    (cone.h:117-137 tests `root < t_min || t_max < root`), and the path goes on from a NaN point for the remaining
-    48 bounces; hittable_list::hit then accepts every object and ends on the last one, until the depth runs out
-    (the sample is black: albedos times zero).  Such a root has nothing to do with where the cone is, so whether a
-    traversal meets it depends on the tree (rays of this kind are outside the parity contract); with leaves of 8 it
-    does here.  From then on no box can prune: the list scan answers those rays (counted in exact_fallbacks)."""
-    monkeypatch.setenv("PT_LEAF_MAX", "8")
-    b = scenes.mixed_scene()
-    ctx.upload(b.desc())
+    """A hit at t = NaN: the reference's comparisons accept it (aarect.h:364-371 tests `t < t_min || t > t_max` and
+    the bounds the same way, Q9), and from then on hittable_list::hit accepts every later entry the ray's line
+    crosses, whatever its distance, until one of them brings the running t back to a number.  No box test can
+    follow that, so every kernel hands such a ray to the list scan (counted in exact_fallbacks).  The case is built,
+    not found: a camera whose field of view underflows (1e-30 degrees) sends every ray from exactly (15, 15, 40)
+    along exactly (0, 0, -10) -- the viewport's extent is absorbed by the coordinates -- and the first list entry is
+    an xz_rect in the plane y = 15, in front of everything else: (k - o.y) / d.y = 0 / 0."""
+    src = scenes.mixed_scene(n=3000, extent=30.0)
+    a = {k: v.copy() for k, v in src.arrays().items()}
+    a["prim_type"][0] = api.XZ_RECT
+    a["prim_param"][0] = [14, 16, 38, 39, 15, 0]
+    b = scenes.ArrayScene(a, src.background, ((15.0, 15.0, 40.0), (15.0, 15.0, 0.0), (0, 1, 0), 1e-30, 1.0, 0.0, 10.0))
     osc = util.oracle_scene(b)
-    x0, y0, w, h = 1100, 398, 6, 4
-    got, st = ctx.render(3840, 2160, 1, 50, sample_offset=4)
-    ref, _ = osc.render(3840, 2160, 1, 50, sample0=4, region=(x0, y0, w, h))
-    crop = got[y0:y0 + h, x0:x0 + w]
-    assert (ref[2, 2] == 0).all() and (crop[2, 2] == 0).all()
-    frac, rmse = _image_close(crop, ref)
-    assert frac <= 0.05 and rmse < 5e-3, (frac, rmse)
-    assert st["exact_fallbacks"] >= 48 and st["rays"] > st["primary_rays"]
-    assert np.isfinite(got).all()
+    o = np.array([[15.0, 15.0, 40.0]], dtype=np.float32)
+    d = np.array([[0.0, 0.0, -10.0]], dtype=np.float32)
+    want = osc.trace(o, d)
+    assert want["nan_flag"][0] == 1 and want["prim"][0] not in (0, api.NO_PRIM)  # a later entry took over from the NaN hit
+    ctx.upload(b.desc())
+    for mode in (api.TRACE_BVH, api.TRACE_BVH_IN_SCENE, api.TRACE_LINEAR):
+        got = ctx.trace(o, d, mode=mode)
+        assert not util.hits_equal(got, want).any(), mode
+        assert mode == api.TRACE_LINEAR or got["flags"][0] & 1
+    w, h, spp, depth = 8, 8, 2, 50
+    ref, rays = osc.render(w, h, spp, depth)
+    got, st = ctx.render(w, h, spp, depth)  # 3000 objects: the streaming kernel
+    frac, rmse = _image_close(got, ref)
+    assert frac == 0 and rmse < 2e-3 and st["rays"] == rays, (frac, rmse, st["rays"], rays)
+    assert st["exact_fallbacks"] >= w * h * spp and np.isfinite(got).all()
+    monkeypatch.setenv("PT_PATHS_STREAM", "0")  # the queue-based kernel, whose traversal is bvh_nearest
+    img, s2 = ctx.render(w, h, spp, depth)
+    assert s2["rays"] == rays and s2["exact_fallbacks"] >= w * h * spp and np.array_equal(img.view(np.uint32), got.view(np.uint32))
 
 
 @pytest.mark.parametrize("which", ["spheres", "mixed"])

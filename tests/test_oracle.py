@@ -29,11 +29,16 @@ def simple(add):
 
 # ---------------------------------------------------------------- random stream
 def test_philox_known_answers():
-    """Random123 kat_vectors for philox4x32_10."""
+    """Random123 kat_vectors for philox4x32_10 (the published default) and philox4x32_7 (the stream's round count)."""
     assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     assert O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
         0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    assert O.PHILOX_ROUNDS == 7
+    assert O.philox([0, 0, 0, 0], [0, 0], 7) == [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]
+    assert O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, 7) == [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]
+    assert O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], 7) == [
+        0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]
 
 
 def test_uniform_range_is_half_open_like_curand():
