@@ -622,11 +622,20 @@ PT_DI void settle_parked(Nearest &nh, bool &need_exact)
 
 // CONES = false compiles the cone case (and with it everything list-order dependent) out: the host
 // selects it for scenes that contain no cone.
-template <bool COUNT, bool CONES, int STRIDE, class Src>
+// KIND says what the scene holds, so that the host can pick a kernel without the code the scene cannot need:
+//   PT_KIND_SPHERES  spheres only: no dispatch on the object tag at all, and no NaN roots (a sphere's quadratic has
+//                    a = |d|^2 > 0 for every ray a render produces);
+//   PT_KIND_NO_CONES any objects but cones: nothing list-order dependent;
+//   PT_KIND_ANY      everything.
+#define PT_KIND_SPHERES 0
+#define PT_KIND_NO_CONES 1
+#define PT_KIND_ANY 2
+template <bool COUNT, int KIND, int STRIDE, class Src>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
                             ProfLanes *prof = nullptr)
 {
+    constexpr bool CONES = KIND == PT_KIND_ANY, SPH = KIND == PT_KIND_SPHERES;
     const float kappa = ray_kappa(src.cone, r.o);
     const BoxRay br = make_box_ray(r, kappa);
     // An axis whose far slot is open (rare).  Only followed up for scenes traversed from HBM, where such a ray
@@ -721,7 +730,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                 float t = 0.0f;
                 bool h = false;
                 const uint32_t type = q.meta & 7u;
-                if (type == PT_SPHERE) { // the common object first: one compare instead of the switch's search
+                if (SPH || type == PT_SPHERE) { // the common object first: one compare instead of the switch's search
                     float hb, disc;
                     if (sphere_discriminant(q, r, hb, disc)) {
                         if (held) release();
@@ -729,6 +738,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
                     }
                     continue;
                 }
+                if (SPH) continue;
                 switch (type) {
                 case PT_XY_RECT: h = hit_rect<2, 0, 1>(q, r, t_min, best_t, t); break;
                 case PT_XZ_RECT: h = hit_rect<1, 0, 2>(q, r, t_min, best_t, t); break;
@@ -766,7 +776,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         }
         // A hit at t = NaN was accepted (the reference's comparisons let it through, and from then on what the scan
         // accepts is a matter of list order: every later entry the ray's line crosses): the list itself answers this ray.
-        if (best_t != best_t) { nan_hit = true; break; }
+        if (!SPH && best_t != best_t) { nan_hit = true; break; }
         if (sp == 0) break;
         cur = (int32_t)stack[(--sp) * STRIDE];
     }
@@ -895,7 +905,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
             uint32_t nb = 0, np = 0, nr = 0;
             GlobalSrc src{sc.nodes, sc.prims, sc.cone};
             if (MODE != PT_TRACE_BVH_IN_SCENE) src.cone.adaptive = 0; // origins from outside the scene's bounds: widest cone
-            h = bvh_nearest<false, true, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+            h = bvh_nearest<false, PT_KIND_ANY, PT_BLOCK>(src, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
             arr = sc.prims;
             if (nr) {
                 flags = 2;
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_raygen(SceneDev sc, PassDev ps, Pa
 
 // Nearest hit for every queued ray.  LDS = true: the workgroup first copies the whole tree and object
 // array into LDS (scenes up to a few thousand objects) and traverses from there.
-template <bool COUNT, bool LDS, int BLOCK, bool CONES>
+template <bool COUNT, bool LDS, int BLOCK, int KIND>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st, uint2 *__restrict__ hits,
                                                      const uint32_t *__restrict__ n_ptr, Counters *cnt)
 {
@@ -1010,8 +1020,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         r.d = V(B.x, B.y, B.z);
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
-        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
+        else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         uint32_t slot = h.slot;
         if (need_exact) {
             // resolved on the list-order records; the top bit of the slot says which array it indexes
@@ -1190,10 +1200,9 @@ struct SliceDev {
     uint32_t pix_per_slice, n_slices; // the largest slice; slices in the table
     const uint2 *extents;             // [n_slices] (first pixel, pixels): decreasing sizes towards the end of the frame
     uint32_t *ticket;
-    uint32_t order; // numbering of a slice's camera rays: 0 pixel-fast (a wave holds one sample of 64 pixels), 1 sample-fast
 };
 
-template <bool COUNT, bool LDS, int BLOCK, bool SORT, bool CONES>
+template <bool COUNT, bool LDS, int BLOCK, bool SORT, int KIND>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
     constexpr int WAVES = BLOCK / 64;
@@ -1240,8 +1249,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     auto trace = [&](const Ray &r) -> HitResult {
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, CONES, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
-        else h = bvh_nearest<COUNT, CONES, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
+        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
+        else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
         if (need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
@@ -1322,10 +1331,13 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                     HitResult h;
                     h.t = 0.0f;
                     h.slot = PT_NO_PRIM;
-                    uint32_t lid0 = i;
+                    // Camera rays are numbered sample-fast: a wave starts with the samples of one or a few pixels, whose rays
+                    // run through the same nodes and mostly end on the same object (C2: 4.5 % faster than one sample of
+                    // 64 neighbouring pixels per wave).  A path reports to rad[sample * npix + pixel] either way.
+                    uint32_t lid0 = 0;
                     if (i < in_count) {
-                        uint32_t s = i / npix, pl = i - s * npix;
-                        if (sl.order) { pl = i / ps.samples; s = i - pl * ps.samples; lid0 = s * npix + pl; }
+                        const uint32_t pl = i / ps.samples, s = i - pl * ps.samples;
+                        lid0 = s * npix + pl;
                         r = camera_ray(sc.cam, ps, pix0 + pl, ps.sample_base + s);
                         mark(1);
                         h = trace(r);
@@ -1481,12 +1493,13 @@ struct BandDev {
     uint32_t run;  // consecutive paths a wave takes at a time
 };
 
-template <bool COUNT, int BLOCK, bool CONES, bool WIDE>
-__global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
+template <bool COUNT, int BLOCK, int KIND, bool WIDE>
+__global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
                                                                            uint32_t *__restrict__ ticket, Counters *cnt,
                                                                            uint32_t serve_min /* lanes waiting for shading or a new path before they are served */, uint32_t phase_bias /* 0: node and leaf steps in every iteration */,
                                                                            unsigned long long *dbg = nullptr /* diagnostic build only */, uint32_t dbg_waves = 0)
 {
+    constexpr bool CONES = KIND == PT_KIND_ANY, SPH = KIND == PT_KIND_SPHERES;
     extern __shared__ float4 s_mem[];
     uint32_t *const stack = reinterpret_cast<uint32_t *>(s_mem) + threadIdx.x;
     if (kProf && dbg && (threadIdx.x & 63u) == 0) dbg[2 * (blockIdx.x * (BLOCK / 64) + threadIdx.x / 64)] = wall_clock64(); // diagnostic build: each wave's start
@@ -1772,7 +1785,7 @@ __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVE
                         // correctly rounded sqrt and divides, the expensive part -- once for every lane that has a candidate,
                         // and once more only where a lane has two.  (The answer does not depend on the order in which the
                         // objects of a leaf are tried: equal t goes to the later list entry either way.)
-                        const bool sph1 = (q.meta & 7u) == PT_SPHERE, sph2 = left > 1 && (q2.meta & 7u) == PT_SPHERE;
+                        const bool sph1 = SPH || (q.meta & 7u) == PT_SPHERE, sph2 = left > 1 && (SPH || (q2.meta & 7u) == PT_SPHERE);
                         float hb1 = 0.0f, disc1 = 0.0f, hb2 = 0.0f, disc2 = 0.0f;
                         const bool cand1 = sph1 && sphere_discriminant(q, r, hb1, disc1);
                         const bool cand2 = sph2 && sphere_discriminant(q2, r, hb2, disc2);
@@ -1786,8 +1799,10 @@ __global__ __launch_bounds__(BLOCK, CONES ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVE
                             const bool h = sphere_roots(r, cand2 ? hb2 : hb1, cand2 ? disc2 : disc1, t_min, nh.best_t, t);
                             nh.take(h, t, cand2 ? first + 1u : first, cand2 ? q2.id : q.id);
                         }
-                        if (!sph1) object_test<CONES>(q, first, r, t_min, t_max, nh);
-                        if (left > 1 && !sph2) object_test<CONES>(q2, first + 1u, r, t_min, t_max, nh);
+                        if (!SPH) {
+                            if (!sph1) object_test<CONES>(q, first, r, t_min, t_max, nh);
+                            if (left > 1 && !sph2) object_test<CONES>(q2, first + 1u, r, t_min, t_max, nh);
+                        }
                     }
                     if (COUNT) np += left > 1 ? 2u : 1u;
                     if (nh.best_t != nh.best_t) { // a hit at t = NaN was accepted: from here on the scan's answer is a matter of list order
@@ -1870,6 +1885,7 @@ struct pt_context {
     pt::BvhBuild tree;      // the installed scene's tree (host copy), refitted by pt_scene_update
     size_t n_mats_alloc = 0;
     bool has_cones = false; // the scene holds at least one cone: the only object whose answer can depend on list order
+    int kind = PT_KIND_ANY; // which kernel variants serve the scene (PT_KIND_*)
     bool lds_scene = true; // traverse small scenes from LDS (PT_RENDER_NO_LDS_SCENE turns it off for A/B runs)
 
     // integrator workspace (grown on demand, kept across calls)
@@ -2189,7 +2205,12 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.cam.lens_radius = c.lens_radius;
     ctx->max_depth_tree = b.max_depth;
     ctx->has_cones = false;
-    for (uint32_t i = 0; i < desc->n_prims; ++i) ctx->has_cones |= desc->prim_type[i] == PT_CONE;
+    bool only_spheres = true;
+    for (uint32_t i = 0; i < desc->n_prims; ++i) {
+        ctx->has_cones |= desc->prim_type[i] == PT_CONE;
+        only_spheres &= desc->prim_type[i] == PT_SPHERE;
+    }
+    ctx->kind = ctx->has_cones ? PT_KIND_ANY : only_spheres ? PT_KIND_SPHERES : PT_KIND_NO_CONES;
     ctx->has_scene = true;
     return PT_OK;
 }
@@ -2245,16 +2266,16 @@ static void launch_intersect(pt_context *ctx, hipStream_t stream, const PathPlan
     if (lds_res) {
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min((max_paths + PT_ISECT_LDS_BLOCK - 1) / PT_ISECT_LDS_BLOCK, (size_t)ctx->n_cu * 2));
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK, true>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK, true>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     } else {
         const uint32_t grid = grid_for(ctx, max_paths);
         const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK, true>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK, true>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     }
 }
 
@@ -2353,12 +2374,18 @@ template <bool COUNT>
 static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
                          const PassDev &ps, const SliceDev &sl, float *d_rgb_sum)
 {
-    const bool cones = ctx->has_cones;
-#define PT_LAUNCH_PATHS(L, B, S, C) hipLaunchKernelGGL((k_paths<COUNT, L, B, S, C>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+    const int kind = ctx->kind;
+#define PT_LAUNCH_PATHS(L, B, S, K) hipLaunchKernelGGL((k_paths<COUNT, L, B, S, K>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_PATHS_K(L, B, S)                                               \
+    do {                                                                         \
+        if (kind == PT_KIND_ANY) PT_LAUNCH_PATHS(L, B, S, PT_KIND_ANY);          \
+        else if (kind == PT_KIND_NO_CONES) PT_LAUNCH_PATHS(L, B, S, PT_KIND_NO_CONES); \
+        else PT_LAUNCH_PATHS(L, B, S, PT_KIND_SPHERES);                          \
+    } while (0)
 #define PT_LAUNCH_PATHS_SC(L, B)                                                 \
     do {                                                                         \
-        if (sort) { if (cones) PT_LAUNCH_PATHS(L, B, true, true); else PT_LAUNCH_PATHS(L, B, true, false); }   \
-        else      { if (cones) PT_LAUNCH_PATHS(L, B, false, true); else PT_LAUNCH_PATHS(L, B, false, false); } \
+        if (sort) PT_LAUNCH_PATHS_K(L, B, true);                                 \
+        else PT_LAUNCH_PATHS_K(L, B, false);                                     \
     } while (0)
     if (lds) {
         if (block == 256) PT_LAUNCH_PATHS_SC(true, 256);
@@ -2368,15 +2395,16 @@ static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool ld
         else PT_LAUNCH_PATHS_SC(false, 512);
     }
 #undef PT_LAUNCH_PATHS_SC
+#undef PT_LAUNCH_PATHS_K
 #undef PT_LAUNCH_PATHS
 }
 
 // The k_paths_stream instance for a launch shape.
-static const void *stream_kernel_for(bool count, int block, bool cones, bool wide)
+static const void *stream_kernel_for(bool count, int block, int kind, bool wide)
 {
 #define PT_STREAM_PTR(C, B, K, W) reinterpret_cast<const void *>(&k_paths_stream<C, B, K, W>)
 #define PT_STREAM_W(C, B, K) (wide ? PT_STREAM_PTR(C, B, K, true) : PT_STREAM_PTR(C, B, K, false))
-#define PT_STREAM_K(C, B) (cones ? PT_STREAM_W(C, B, true) : PT_STREAM_W(C, B, false))
+#define PT_STREAM_K(C, B) (kind == PT_KIND_ANY ? PT_STREAM_W(C, B, PT_KIND_ANY) : kind == PT_KIND_NO_CONES ? PT_STREAM_W(C, B, PT_KIND_NO_CONES) : PT_STREAM_W(C, B, PT_KIND_SPHERES))
 #define PT_STREAM_B(C) (block == 256 ? PT_STREAM_K(C, 256) : PT_STREAM_K(C, 512))
     return count ? PT_STREAM_B(true) : PT_STREAM_B(false);
 #undef PT_STREAM_B
@@ -2419,7 +2447,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         per_cu = std::min<int>(waves_per_simd * 4 * 64 / block, (int)((160 * 1024) / std::max<size_t>(lds_used, 1)));
         if (stream_kernel) { // what the runtime will really keep resident (its cone variants take more registers than the budget)
             int fit = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, stream_kernel_for(count, block, ctx->has_cones, wide), block, stream_stack_bytes) == hipSuccess && fit > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, stream_kernel_for(count, block, ctx->kind, wide), block, stream_stack_bytes) == hipSuccess && fit > 0)
                 per_cu = std::min(per_cu, fit);
         }
         per_cu = std::max(per_cu, 1);
@@ -2455,7 +2483,6 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
         ps.max_depth = pr->max_depth;
         const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 32)));
-        const bool cones = ctx->has_cones;
         // One kind of step per iteration (the two kinds share no code: run in the same iteration each executes with the
         // lanes of the other masked off), leaf steps as soon as a third of the traversing lanes wait for one: 100k mixed
         // objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for PT_STREAM_PHASE 0 (both kinds every iteration) / 2 / 3 / 4 / 6,
@@ -2490,7 +2517,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
                     Counters *a_cnt = ctx->d_cnt;
                     uint32_t a_serve = serve_min, a_phase = phase_bias, a_dbgw = (uint32_t)dbg_waves;
                     void *args[] = {&a_sc, &ps, &band, &a_rad, &a_ticket, &a_cnt, &a_serve, &a_phase, &dbg, &a_dbgw};
-                    PT_HIP(ctx, hipLaunchKernel(stream_kernel_for(count, block, cones, wide), dim3(grid), dim3(block), args, stream_stack_bytes, stream));
+                    PT_HIP(ctx, hipLaunchKernel(stream_kernel_for(count, block, ctx->kind, wide), dim3(grid), dim3(block), args, stream_stack_bytes, stream));
                 }
                 tm.end();
                 hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, band.npix)), dim3(PT_BLOCK), 0, stream, ps, (const float *)ctx->d_prad, d_rgb_sum, (const uint32_t *)nullptr, ctx->d_cnt,
@@ -2622,7 +2649,6 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
     sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.extents = ctx->d_extents; sl.ticket = ctx->d_ticket;
-    sl.order = (uint32_t)env_int("PT_PATHS_ORDER", 0);
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
