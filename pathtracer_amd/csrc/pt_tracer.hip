@@ -309,6 +309,7 @@ struct GlobalSrc {
     const BvhNode *nodes;
     const PrimRec *prims;
     pt::ConeParams cone;
+    static __device__ __forceinline__ void adapt(BoxRay &) {}
     // near / far plane pairs of node i for this ray, and the children's references
     __device__ __forceinline__ void planes(int32_t i, const BoxRay &br, float2 &nx, float2 &ny, float2 &nz, float2 &fx, float2 &fy,
                                            float2 &fz, int32_t &c0, int32_t &c1) const
@@ -322,26 +323,35 @@ struct GlobalSrc {
         w0 = pp[0]; w1 = pp[1];
     }
 };
+// The LDS copy of a node is 80 bytes: per axis the six floats (hi0, hi1, lo0, lo1, hi0, hi1) -- the children's upper
+// planes stored twice around their lower ones -- then the two references.  The four floats a ray needs of an axis,
+// (near0, near1, far0, far1), are then consecutive whichever way it runs: from byte 8 of the axis for a positive
+// direction (lo, lo, hi, hi), from byte 0 for a negative one (hi, hi, lo, lo).  One address per axis (node base + a
+// per-ray offset) serves both reads, four address instructions per visit instead of thirteen; and the 80-byte stride
+// spreads the lanes of a read over all sixteen 16-byte bank slots, which a 64-byte stride would not.
+#define PT_LDS_NODE_BYTES 80u
 struct LdsSrc {
     static constexpr bool in_lds = true;
-    const float4 *nodes; // 4 planes of n_nodes
+    const char *nodes;   // n_nodes records of PT_LDS_NODE_BYTES
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
     pt::ConeParams cone;
+    // the ray's byte offsets of (near, far) within a record, per axis
+    static __device__ __forceinline__ void adapt(BoxRay &br)
+    {
+        br.sx = br.sx ^ 8u;
+        br.sy = 24u + (br.sy ^ 8u);
+        br.sz = 48u + (br.sz ^ 8u);
+    }
     __device__ __forceinline__ void planes(int32_t i, const BoxRay &br, float2 &nx, float2 &ny, float2 &nz, float2 &fx, float2 &fy,
                                            float2 &fz, int32_t &c0, int32_t &c1) const
     {
-        // plane a holds the quad of axis a of every node; the near pair sits at byte 0 or 8 of the quad
-        const char *base = reinterpret_cast<const char *>(nodes + i);
-        const uint32_t stride = n_nodes * 16u;
-        const char *px = base + br.sx, *py = base + stride + br.sy, *pz = base + 2u * stride + br.sz;
-        nx = *reinterpret_cast<const float2 *>(px);
-        ny = *reinterpret_cast<const float2 *>(py);
-        nz = *reinterpret_cast<const float2 *>(pz);
-        fx = *reinterpret_cast<const float2 *>(base + (br.sx ^ 8u));
-        fy = *reinterpret_cast<const float2 *>(base + stride + (br.sy ^ 8u));
-        fz = *reinterpret_cast<const float2 *>(base + 2u * stride + (br.sz ^ 8u));
-        const int2 c = *reinterpret_cast<const int2 *>(base + 3u * stride);
+        const char *base = nodes + (uint32_t)i * PT_LDS_NODE_BYTES;
+        const char *px = base + br.sx, *py = base + br.sy, *pz = base + br.sz;
+        nx = *reinterpret_cast<const float2 *>(px); fx = *reinterpret_cast<const float2 *>(px + 8);
+        ny = *reinterpret_cast<const float2 *>(py); fy = *reinterpret_cast<const float2 *>(py + 8);
+        nz = *reinterpret_cast<const float2 *>(pz); fz = *reinterpret_cast<const float2 *>(pz + 8);
+        const int2 c = *reinterpret_cast<const int2 *>(base + 72);
         c0 = c.x;
         c1 = c.y;
     }
@@ -350,6 +360,35 @@ struct LdsSrc {
         w0 = prims[slot]; w1 = prims[n_prims + slot];
     }
 };
+
+// Copies the scene into the workgroup's LDS (nodes in the 80-byte form, objects as two planes of quads) and returns
+// the first byte after it.  The caller synchronises the workgroup before traversing.
+template <int BLOCK>
+PT_DI char *lds_scene_copy(const SceneDev &sc, float4 *s_mem, LdsSrc &lsrc)
+{
+    char *s_nodes = reinterpret_cast<char *>(s_mem);
+    float4 *s_prims = reinterpret_cast<float4 *>(s_nodes + ((sc.n_nodes * PT_LDS_NODE_BYTES + 15u) & ~15u));
+    const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
+    for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) {
+        const float4 q = gn[i]; // quarter i & 3 of node i >> 2: an axis quad (lo0, lo1, hi0, hi1), or the references
+        float2 *dst = reinterpret_cast<float2 *>(s_nodes + (i >> 2) * PT_LDS_NODE_BYTES + (i & 3u) * 24u);
+        if ((i & 3u) == 3u) {
+            dst[0] = make_float2(q.x, q.y);
+        } else {
+            dst[0] = make_float2(q.z, q.w);
+            dst[1] = make_float2(q.x, q.y);
+            dst[2] = make_float2(q.z, q.w);
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
+    lsrc.nodes = s_nodes;
+    lsrc.prims = s_prims;
+    return reinterpret_cast<char *>(s_prims + 2 * sc.n_prims);
+}
+static size_t lds_scene_size(uint32_t n_nodes, uint32_t n_prims)
+{
+    return (((size_t)n_nodes * PT_LDS_NODE_BYTES + 15u) & ~(size_t)15u) + (size_t)n_prims * 32;
+}
 
 #define PT_SCAN_MAX 16 // candidates the exact replay keeps per ray
 
@@ -637,7 +676,8 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
 {
     constexpr bool CONES = KIND == PT_KIND_ANY, SPH = KIND == PT_KIND_SPHERES;
     const float kappa = ray_kappa(src.cone, r.o);
-    const BoxRay br = make_box_ray(r, kappa);
+    BoxRay br = make_box_ray(r, kappa);
+    Src::adapt(br);
     // An axis whose far slot is open (rare).  Only followed up for scenes traversed from HBM, where such a ray
     // otherwise walks a large part of the tree; on the LDS-resident scenes (at most 1000 objects) the test costs
     // the kernel more registers than those rays cost it time (C2: 20.9 -> 22.1 ms with it).
@@ -997,13 +1037,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     uint32_t *s_stack;
     LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.cone};
     if (LDS) {
-        float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
-        s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
-        const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
-        for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) s_nodes[(i & 3u) * sc.n_nodes + (i >> 2)] = gn[i];
-        for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
-        lsrc.nodes = s_nodes;
-        lsrc.prims = s_prims;
+        s_stack = reinterpret_cast<uint32_t *>(lds_scene_copy<BLOCK>(sc, s_mem, lsrc));
         __syncthreads();
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
@@ -1214,13 +1248,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     uint32_t *s_stack;
     LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.cone};
     if (LDS) {
-        float4 *s_nodes = s_mem, *s_prims = s_mem + 4 * sc.n_nodes;
-        s_stack = reinterpret_cast<uint32_t *>(s_prims + 2 * sc.n_prims);
-        const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
-        for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) s_nodes[(i & 3u) * sc.n_nodes + (i >> 2)] = gn[i];
-        for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
-        lsrc.nodes = s_nodes;
-        lsrc.prims = s_prims;
+        s_stack = reinterpret_cast<uint32_t *>(lds_scene_copy<BLOCK>(sc, s_mem, lsrc));
     } else {
         s_stack = reinterpret_cast<uint32_t *>(s_mem);
     }
@@ -2256,7 +2284,7 @@ static uint32_t grid_for(const pt_context *ctx, size_t n)
 static size_t lds_scene_bytes(const pt_context *ctx)
 {
     const SceneDev &sc = ctx->sc;
-    size_t b = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32 + (size_t)sc.stack_cap * PT_ISECT_LDS_BLOCK * 4;
+    size_t b = lds_scene_size(sc.n_nodes, sc.n_prims) + (size_t)sc.stack_cap * PT_ISECT_LDS_BLOCK * 4;
     return b <= 80 * 1024 ? b : 0; // two workgroups per CU must fit in 160 KB
 }
 
@@ -2422,7 +2450,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const bool want_lds = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0 && env_int("PT_PATHS_LDS", 1) != 0;
     const bool sort = (pr->flags & PT_RENDER_NO_SORT) == 0 && env_int("PT_PATHS_SORT", 0) != 0; // measured slower on the spheres scene: opt-in
     const SceneDev &sc = ctx->sc;
-    const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * 32;
+    const size_t scene_bytes = lds_scene_size(sc.n_nodes, sc.n_prims);
     int block = env_int("PT_PATHS_BLOCK", 0);
     if (block != 256 && block != 512) {
         // LDS-resident scenes: 512 (one scene copy per 8 waves).  Scenes traversed from HBM: 256 measured best without cones;
