@@ -9,8 +9,11 @@
  * exits the process (the reference's checkCudaErrors, commons.h:68-77, prints and exit(99)s).
  * The caller owns host buffers; the library owns device memory except where a parameter is
  * documented as a caller-provided device pointer.  One context serves one GPU and is used from
- * one host thread at a time.  Multi-GPU jobs run one process (one context) per GPU and combine the
- * linear accumulation buffers themselves (RCCL all-reduce), see pt_render_device.
+ * one host thread at a time.  Calls that enqueue work on a stream and return (pt_render_device,
+ * pt_trace_rays_device) share the context's workspace: the library orders each such call behind the
+ * previous one on the same context (an event wait), whatever streams they use.  Multi-GPU jobs run one
+ * context per GPU and combine the linear accumulation buffers with an all-reduce: pt_group_* below does
+ * so in one process over RCCL; one process per GPU with pt_render_device works as well.
  */
 #ifndef PT_API_H
 #define PT_API_H
@@ -90,7 +93,13 @@ enum {
     PT_RENDER_NO_SORT = 2u,     /* never use the block-local material sort (it is opt-in: environment PT_PATHS_SORT=1) */
     PT_RENDER_COUNT_TESTS = 4u, /* count box / object tests per ray (slower; fills pt_stats.box_tests / prim_tests) */
     PT_RENDER_NO_LDS_SCENE = 8u, /* traverse from global memory even when the scene would fit in LDS */
-    PT_RENDER_SPLIT_KERNELS = 16u /* one launch per stage and bounce over global queues instead of the persistent-workgroup kernel */
+    PT_RENDER_SPLIT_KERNELS = 16u, /* one launch per stage and bounce over global queues instead of the persistent-workgroup kernel */
+    /* Cull tree boxes by the objects' exact geometry only (no ray cone, see pt_scene_ray_cone).  The default cone keeps
+     * the hits the reference's fp32 quadratics (sphere.h:85-101, cylinder.h:96-123, cone.h:101-129) report outside the exact
+     * surfaces far from the ray origin, at up to twice the traversal cost on scenes hundreds of units across.  With this
+     * flag a ray may lose such a hit: every lost or changed hit is one whose discriminant is rounding noise
+     * (|discriminant| < 1e-4 * half_b^2), everything else stays bit-exact. */
+    PT_RENDER_GEOMETRIC_CULL = 32u
 };
 
 typedef struct pt_stats {
@@ -104,9 +113,34 @@ typedef struct pt_stats {
     uint32_t passes;
     double ms_paths; /* only with PT_RENDER_STAGE_TIMES: summed k_paths launch time */
     uint64_t exact_replays; /* rays whose list-order dependent answer was replayed over their candidate objects */
+    uint32_t kernel;        /* which pipeline rendered the call: PT_KERNEL_* */
+    uint32_t reserved;
 } pt_stats;
+enum { PT_KERNEL_PATHS = 1 /* k_paths */, PT_KERNEL_PATHS_STREAM = 2 /* k_paths_stream + k_film */, PT_KERNEL_SPLIT = 3 /* one launch per stage and bounce */ };
 
 typedef struct pt_context pt_context;
+
+/* Scheduling and tree-shape parameters of a context.  They never change what is computed (every setting gives the list
+ * scan's answers and, for renders, bit-identical images); they exist for A/B measurements and tests.  A negative field
+ * means "the library's own choice".  Nothing in the reference corresponds: it has one kernel shape, main.cu:111-117. */
+typedef struct pt_tuning {
+    int32_t leaf_max;          /* objects per tree leaf, 1..8; applies from the next pt_scene_upload */
+    int32_t wide_nodes;        /* 0 / 1: four-wide quantised nodes for scenes traversed from HBM; next pt_scene_upload */
+    int32_t pipeline;          /* 0 queue-based persistent workgroups (k_paths), 1 streaming lanes (k_paths_stream) */
+    int32_t lds_scene;         /* 0: never copy the scene into LDS */
+    int32_t block;             /* threads per workgroup: 256 or 512 */
+    int32_t workgroups_per_cu; /* 1..16 */
+    int32_t slice_paths;       /* paths per slice of k_paths, 64..2^22 */
+    int32_t slice_taper;       /* 1..64: the last slices of a frame shrink to 1/taper of a full one */
+    int32_t sort_by_material;  /* 0 / 1: block-local material sort before shading in k_paths */
+    int32_t stream_serve_min;  /* 1..64 lanes waiting before k_paths_stream shades them */
+    int32_t stream_phase;      /* 0..16: 0 both kinds of step per iteration, n: a leaf step once n/4 of the traversing lanes wait for one */
+    int32_t stream_tile;       /* 64..4096, a multiple of 64: pixels per tile of k_paths_stream's path numbering */
+    int32_t stream_run;        /* 64..65536: consecutive paths a wave takes at a time */
+} pt_tuning;
+void pt_tuning_default(pt_tuning *t); /* every field negative */
+/* PT_ERR_INVALID (and no change) if a non-negative field is out of its range. */
+pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t);
 
 /* Replaces the implicit device 0 / cudaDeviceReset life cycle of main.cu:106-220. */
 pt_status pt_context_create(int device_id, pt_context **out);
@@ -163,6 +197,9 @@ pt_status pt_film_finalize(const float *rgb_sum, int32_t width, int32_t height, 
  * indices in leaf order.  Pass NULLs to query the sizes. */
 pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
                             uint32_t *order_out);
+/* The same with a given leaf size (1..8) instead of the one pt_scene_upload would choose for the scene. */
+pt_status pt_bvh_build_host_leaf(const pt_scene_desc *desc, uint32_t leaf_max, uint32_t *n_nodes, uint32_t *max_depth,
+                                 void *nodes_out, uint32_t *order_out);
 
 /* The tree pt_scene_update leaves behind (host-side tests, no GPU needed): built for `before`, refitted to
  * `after` (same number of objects).  Outputs as for pt_bvh_build_host. */

@@ -17,14 +17,16 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ER
 SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
 TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE = 0, 1, 2
-RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS = 1, 2, 4, 8, 16
+RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS, RENDER_GEOMETRIC_CULL = 1, 2, 4, 8, 16, 32
+KERNEL_NAMES = {0: "-", 1: "k_paths", 2: "k_paths_stream", 3: "k_raygen/k_intersect/k_shade/k_film"}
 NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
 EXPORTS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload", "pt_scene_update",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
-    "pt_bvh_build_host", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
+    "pt_bvh_build_host", "pt_bvh_build_host_leaf", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
+    "pt_tuning_default", "pt_context_configure",
 ]
 
 
@@ -66,10 +68,20 @@ class PtStats(C.Structure):
         ("exact_fallbacks", C.c_uint64), ("ms_total", C.c_double), ("ms_raygen", C.c_double),
         ("ms_intersect", C.c_double), ("ms_shade", C.c_double), ("ms_film", C.c_double),
         ("launches_intersect", C.c_uint32), ("passes", C.c_uint32), ("ms_paths", C.c_double), ("exact_replays", C.c_uint64),
+        ("kernel", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+TUNING_FIELDS = ("leaf_max", "wide_nodes", "pipeline", "lds_scene", "block", "workgroups_per_cu", "slice_paths", "slice_taper",
+                 "sort_by_material", "stream_serve_min", "stream_phase", "stream_tile", "stream_run")
+
+
+class PtTuning(C.Structure):
+    """pt_tuning: a negative field leaves the choice to the library."""
+    _fields_ = [(n, C.c_int32) for n in TUNING_FIELDS]
 
 
 HIT_DTYPE = np.dtype(
@@ -130,6 +142,10 @@ def lib():
         L.pt_scene_ray_cone.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtRayCone)]
         L.pt_bvh_wide_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
         L.pt_bvh_refit_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.pt_bvh_build_host_leaf.argtypes = [C.POINTER(PtSceneDesc), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.pt_tuning_default.argtypes = [C.POINTER(PtTuning)]
+        L.pt_tuning_default.restype = None
+        L.pt_context_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
         _lib = L
     return _lib
 
@@ -183,15 +199,22 @@ class SceneDesc:
         self.c = d
 
 
-def bvh_build_host(desc):
-    """Builds the tree pt_scene_upload builds, on the host; returns (nodes, order, max_depth)."""
+def bvh_build_host(desc, leaf_max=None):
+    """Builds the tree pt_scene_upload builds (or one with leaves of up to leaf_max objects), on the host;
+    returns (nodes, order, max_depth)."""
     n_nodes, depth = C.c_uint32(0), C.c_uint32(0)
-    st = lib().pt_bvh_build_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), None, None)
+
+    def call(nodes_p, order_p):
+        if leaf_max is None:
+            return lib().pt_bvh_build_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), nodes_p, order_p)
+        return lib().pt_bvh_build_host_leaf(C.byref(desc.c), int(leaf_max), C.byref(n_nodes), C.byref(depth), nodes_p, order_p)
+
+    st = call(None, None)
     if st != PT_OK:
         raise PtError(st, "pt_bvh_build_host")
     nodes = np.zeros(n_nodes.value, dtype=NODE_DTYPE)
     order = np.zeros(desc.c.n_prims, dtype=np.uint32)
-    st = lib().pt_bvh_build_host(C.byref(desc.c), C.byref(n_nodes), C.byref(depth), nodes.ctypes.data, order.ctypes.data)
+    st = call(nodes.ctypes.data, order.ctypes.data)
     if st != PT_OK:
         raise PtError(st, "pt_bvh_build_host")
     return nodes, order, depth.value
@@ -284,6 +307,31 @@ class Context:
 
     def upload(self, desc):
         self._check(lib().pt_scene_upload(self._h, C.byref(desc.c)))
+
+    def configure(self, **fields):
+        """pt_context_configure: scheduling / tree-shape parameters (TUNING_FIELDS); unnamed ones go back to the
+        library's own choice.  leaf_max and wide_nodes apply from the next upload()."""
+        t = PtTuning()
+        lib().pt_tuning_default(C.byref(t))
+        for k, v in fields.items():
+            if k not in TUNING_FIELDS:
+                raise ValueError("unknown tuning field %r" % k)
+            setattr(t, k, int(v))
+        self._check(lib().pt_context_configure(self._h, C.byref(t)))
+
+    def tuned(self, **fields):
+        """Context manager: configure(**fields) inside, the library's defaults again afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.configure(**fields)
+            try:
+                yield self
+            finally:
+                self.configure()
+
+        return cm()
 
     def update(self, desc):
         """pt_scene_update: a changed scene with the same number of objects; the tree is refitted, not rebuilt."""

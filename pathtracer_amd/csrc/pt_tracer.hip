@@ -1942,22 +1942,22 @@ struct pt_context {
     pt_hit *d_rh = nullptr;
     size_t cap_rays = 0;
     std::vector<hipEvent_t> events;
+    pt_tuning tune;              // pt_context_configure; negative = the library's own choice
+    hipEvent_t last_done = nullptr; // end of the last call that enqueued work using the workspace above
+    bool have_last = false;
+    struct StreamPlan *stream_plan = nullptr; // launch shape of the streaming pipeline for the installed scene (pt_render_device_noalloc)
 };
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int tuned(int32_t v, int dflt) { return v >= 0 ? (int)v : dflt; }
 
 // Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
 // lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 1.  A leaf step
 // costs a wave the object code of every kind of object its lanes hold, once per position in the leaf that any lane
 // still has an object at; a node visit costs a fifth of that.  (1M spheres 3.04 / 3.20 / 3.27 Grays/s for 3 / 2 / 1,
-// 100k mixed objects 2.73 / 2.88 / 3.25 / 3.46 for 4 / 3 / 2 / 1.)  PT_LEAF_MAX overrides (tuning).
-static uint32_t leaf_max_for(const pt_scene_desc *desc)
+// 100k mixed objects 2.73 / 2.88 / 3.25 / 3.46 for 4 / 3 / 2 / 1.)  pt_tuning.leaf_max overrides.
+static uint32_t leaf_max_for(const pt_scene_desc *desc, const pt_tuning *tune = nullptr)
 {
-    if (const char *v = getenv("PT_LEAF_MAX")) return (uint32_t)atoi(v);
+    if (tune && tune->leaf_max > 0) return (uint32_t)tune->leaf_max;
     return desc->n_prims > 1000u ? 1u : (uint32_t)PT_LEAF_MAX;
 }
 
@@ -1989,7 +1989,45 @@ extern "C" pt_status pt_context_create(int device_id, pt_context **out)
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PT_ERR_DEVICE; }
     if (hipMalloc(&ctx->d_cnt, sizeof(Counters)) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
+    if (hipEventCreateWithFlags(&ctx->last_done, hipEventDisableTiming) != hipSuccess) { hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
+    pt_tuning_default(&ctx->tune);
     *out = ctx;
+    return PT_OK;
+}
+
+extern "C" void pt_tuning_default(pt_tuning *t)
+{
+    if (!t) return;
+    int32_t *f = reinterpret_cast<int32_t *>(t);
+    for (size_t i = 0; i < sizeof(pt_tuning) / sizeof(int32_t); ++i) f[i] = -1;
+}
+
+static void drop_stream_plan(pt_context *ctx);
+static void make_stream_plan(pt_context *ctx);
+static pt_status order_behind_last(pt_context *ctx, hipStream_t stream);
+static pt_status mark_last(pt_context *ctx, hipStream_t stream);
+
+extern "C" pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t)
+{
+    if (!ctx || !t) return PT_ERR_INVALID;
+    auto in = [](int32_t v, int lo, int hi) { return v < 0 || (v >= lo && v <= hi); };
+    const char *bad = nullptr;
+    if (!in(t->leaf_max, 1, 8)) bad = "leaf_max (1..8)";
+    else if (!in(t->wide_nodes, 0, 1)) bad = "wide_nodes (0, 1)";
+    else if (!in(t->pipeline, 0, 1)) bad = "pipeline (0, 1)";
+    else if (!in(t->lds_scene, 0, 1)) bad = "lds_scene (0, 1)";
+    else if (!(t->block < 0 || t->block == 256 || t->block == 512)) bad = "block (256, 512)";
+    else if (!in(t->workgroups_per_cu, 1, 16)) bad = "workgroups_per_cu (1..16)";
+    else if (!in(t->slice_paths, 64, 1 << 22)) bad = "slice_paths (64..2^22)";
+    else if (!in(t->slice_taper, 1, 64)) bad = "slice_taper (1..64)";
+    else if (!in(t->sort_by_material, 0, 1)) bad = "sort_by_material (0, 1)";
+    else if (!in(t->stream_serve_min, 1, 64)) bad = "stream_serve_min (1..64)";
+    else if (!in(t->stream_phase, 0, 16)) bad = "stream_phase (0..16)";
+    else if (!(t->stream_tile < 0 || (t->stream_tile >= 64 && t->stream_tile <= 4096 && t->stream_tile % 64 == 0))) bad = "stream_tile (64..4096, a multiple of 64)";
+    else if (!in(t->stream_run, 64, 65536)) bad = "stream_run (64..65536)";
+    if (bad) return fail(ctx, PT_ERR_INVALID, std::string("pt_tuning: out of range: ") + bad);
+    ctx->tune = *t;
+    if (hipSetDevice(ctx->device) == hipSuccess) make_stream_plan(ctx);
     return PT_OK;
 }
 
@@ -2021,6 +2059,8 @@ extern "C" void pt_context_destroy(pt_context *ctx)
     hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad); hipFree(ctx->d_ticket);
     hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
     for (hipEvent_t e : ctx->events) hipEventDestroy(e);
+    if (ctx->last_done) hipEventDestroy(ctx->last_done);
+    drop_stream_plan(ctx);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -2097,10 +2137,17 @@ static void make_records(const pt_scene_desc &d, const std::vector<uint32_t> &or
 extern "C" pt_status pt_bvh_build_host(const pt_scene_desc *desc, uint32_t *n_nodes, uint32_t *max_depth, void *nodes_out,
                                        uint32_t *order_out)
 {
+    if (!desc) return PT_ERR_INVALID;
+    return pt_bvh_build_host_leaf(desc, leaf_max_for(desc), n_nodes, max_depth, nodes_out, order_out);
+}
+
+extern "C" pt_status pt_bvh_build_host_leaf(const pt_scene_desc *desc, uint32_t leaf_max, uint32_t *n_nodes, uint32_t *max_depth,
+                                            void *nodes_out, uint32_t *order_out)
+{
     std::string e = validate_desc(desc);
-    if (!e.empty()) return PT_ERR_INVALID;
+    if (!e.empty() || leaf_max < 1 || leaf_max > 8) return PT_ERR_INVALID;
     pt::BvhBuild b;
-    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
+    e = pt::build_bvh(*desc, leaf_max, b);
     if (!e.empty()) return PT_ERR_INVALID;
     if (n_nodes) *n_nodes = (uint32_t)b.nodes.size();
     if (max_depth) *max_depth = b.max_depth;
@@ -2155,9 +2202,10 @@ extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *o
     return PT_OK;
 }
 
-// Copies a built (or refitted) tree and the scene's records to the device and points the context at them.
-// `fresh` allocates; otherwise the buffers of the previous upload (same object count) are overwritten.
-static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const pt::BvhBuild &b, bool fresh)
+// Copies a built (or refitted) tree and the scene's records to the device and points the context at them.  Everything
+// goes into new buffers first; the installed scene (if any) is replaced, and its buffers freed, only after every copy
+// has succeeded, so a failure leaves the context rendering what it rendered before.
+static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const pt::BvhBuild &b)
 {
     if (b.max_depth > 96) return fail(ctx, PT_ERR_LIMIT, "BVH deeper than 96 levels");
     std::vector<PrimRec> leaf, list;
@@ -2167,49 +2215,52 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipDeviceSynchronize());
     const size_t nb = b.nodes.size() * sizeof(BvhNode), pb = leaf.size() * sizeof(PrimRec), mb = mats.size() * sizeof(float4);
-    if (fresh) {
-        free_scene(ctx);
-        PT_HIP(ctx, hipMalloc(&ctx->d_nodes, nb));
-        PT_HIP(ctx, hipMalloc(&ctx->d_prims, pb + sizeof(PrimRec))); // one record of padding: k_paths_stream fetches objects in pairs
-        PT_HIP(ctx, hipMemset(reinterpret_cast<char *>(ctx->d_prims) + pb, 0, sizeof(PrimRec)));
-        PT_HIP(ctx, hipMalloc(&ctx->d_prims_list, pb));
-        PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
-        ctx->n_mats_alloc = mats.size();
-    } else if (mats.size() > ctx->n_mats_alloc) {
-        hipFree(ctx->d_mats);
-        ctx->d_mats = nullptr;
-        PT_HIP(ctx, hipMalloc(&ctx->d_mats, mb));
-        ctx->n_mats_alloc = mats.size();
+    bool any_cone = false, only_spheres = true;
+    for (uint32_t i = 0; i < desc->n_prims; ++i) {
+        any_cone |= desc->prim_type[i] == PT_CONE;
+        only_spheres &= desc->prim_type[i] == PT_SPHERE;
     }
-    PT_HIP(ctx, hipMemcpy(ctx->d_nodes, b.nodes.data(), nb, hipMemcpyHostToDevice));
-    PT_HIP(ctx, hipMemcpy(ctx->d_prims, leaf.data(), pb, hipMemcpyHostToDevice));
-    PT_HIP(ctx, hipMemcpy(ctx->d_prims_list, list.data(), pb, hipMemcpyHostToDevice));
-    PT_HIP(ctx, hipMemcpy(ctx->d_mats, mats.data(), mb, hipMemcpyHostToDevice));
     // Scenes too large for LDS are rendered from the four-wide form of the tree (k_paths_stream): 1.8 times fewer
     // node fetches per ray, 1M spheres 2.82 -> 3.47 Grays/s.  Not for scenes with cones, whose kernel variant
-    // has no registers to spare for the four-child step (100k mixed objects: 3.68 -> 2.03).  PT_STREAM_WIDE=0|1 overrides.
-    bool any_cone = false;
-    for (uint32_t i = 0; i < desc->n_prims; ++i) any_cone |= desc->prim_type[i] == PT_CONE;
-    ctx->sc.wide = nullptr;
-    ctx->sc.wide_stack_cap = 0;
-    if (nb + pb > 48 * 1024 && env_int("PT_STREAM_WIDE", any_cone ? 0 : 1) != 0) {
-        pt::WideBuild wb;
-        pt::make_wide(b, wb);
-        if (wb.nodes.size() > ctx->n_wide_alloc) {
-            hipFree(ctx->d_wide);
-            ctx->d_wide = nullptr; ctx->n_wide_alloc = 0;
-            PT_HIP(ctx, hipMalloc(&ctx->d_wide, wb.nodes.size() * sizeof(pt::WideNode)));
-            ctx->n_wide_alloc = wb.nodes.size();
-        }
-        PT_HIP(ctx, hipMemcpy(ctx->d_wide, wb.nodes.data(), wb.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice));
-        ctx->sc.wide = ctx->d_wide;
-        // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
-        // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
-        ctx->sc.wide_stack_cap = std::min(31u, 3u * wb.max_depth + 1u);
-        ctx->wide_depth = wb.max_depth;
+    // has no registers to spare for the four-child step (100k mixed objects: 3.68 -> 2.03).  pt_tuning.wide_nodes overrides.
+    pt::WideBuild wb;
+    const bool want_wide = nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, any_cone ? 0 : 1) != 0;
+    if (want_wide) pt::make_wide(b, wb);
+
+    BvhNode *n_nodes = nullptr;
+    PrimRec *n_prims = nullptr, *n_list = nullptr;
+    float4 *n_mats = nullptr, *n_wide = nullptr;
+    auto upload = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMalloc(&n_nodes, nb)) != hipSuccess) return e;
+        if ((e = hipMalloc(&n_prims, pb + sizeof(PrimRec))) != hipSuccess) return e; // one record of padding: k_paths_stream fetches objects in pairs
+        if ((e = hipMalloc(&n_list, pb)) != hipSuccess) return e;
+        if ((e = hipMalloc(&n_mats, mb)) != hipSuccess) return e;
+        if (want_wide && (e = hipMalloc(&n_wide, wb.nodes.size() * sizeof(pt::WideNode))) != hipSuccess) return e;
+        if ((e = hipMemset(reinterpret_cast<char *>(n_prims) + pb, 0, sizeof(PrimRec))) != hipSuccess) return e;
+        if ((e = hipMemcpy(n_nodes, b.nodes.data(), nb, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMemcpy(n_prims, leaf.data(), pb, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMemcpy(n_list, list.data(), pb, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMemcpy(n_mats, mats.data(), mb, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if (want_wide && (e = hipMemcpy(n_wide, wb.nodes.data(), wb.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        return hipSuccess;
+    };
+    const hipError_t ue = upload();
+    if (ue != hipSuccess) {
+        hipFree(n_nodes); hipFree(n_prims); hipFree(n_list); hipFree(n_mats); hipFree(n_wide);
+        return fail(ctx, PT_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(ue));
     }
+    free_scene(ctx); // the previous scene's buffers
+    ctx->d_nodes = n_nodes; ctx->d_prims = n_prims; ctx->d_prims_list = n_list; ctx->d_mats = n_mats; ctx->d_wide = n_wide;
+    ctx->n_mats_alloc = mats.size();
+    ctx->n_wide_alloc = want_wide ? wb.nodes.size() : 0;
 
     SceneDev &sc = ctx->sc;
+    sc.wide = n_wide;
+    // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
+    // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
+    sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 1u) : 0u;
+    ctx->wide_depth = want_wide ? wb.max_depth : 0u;
     sc.nodes = ctx->d_nodes;
     sc.prims = ctx->d_prims;
     sc.prims_list = ctx->d_prims_list;
@@ -2218,11 +2269,6 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 1);
     sc.cone = b.cone;
-    if (const char *kv = getenv("PT_KAPPA_SCALE")) { // diagnostic: < 1 voids the exactness guarantee
-        sc.cone.kappa_max *= (float)atof(kv);
-        sc.cone.kappa_min *= (float)atof(kv);
-    }
-    if (env_int("PT_KAPPA_ADAPTIVE", 1) == 0) sc.cone.adaptive = 0; // diagnostic: every ray gets kappa_max
     const pt_camera &c = desc->camera;
     for (int k = 0; k < 3; ++k) {
         sc.cam.origin[k] = c.origin[k]; sc.cam.llc[k] = c.lower_left_corner[k];
@@ -2232,14 +2278,11 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     }
     sc.cam.lens_radius = c.lens_radius;
     ctx->max_depth_tree = b.max_depth;
-    ctx->has_cones = false;
-    bool only_spheres = true;
-    for (uint32_t i = 0; i < desc->n_prims; ++i) {
-        ctx->has_cones |= desc->prim_type[i] == PT_CONE;
-        only_spheres &= desc->prim_type[i] == PT_SPHERE;
-    }
-    ctx->kind = ctx->has_cones ? PT_KIND_ANY : only_spheres ? PT_KIND_SPHERES : PT_KIND_NO_CONES;
+    ctx->has_cones = any_cone;
+    ctx->kind = any_cone ? PT_KIND_ANY : only_spheres ? PT_KIND_SPHERES : PT_KIND_NO_CONES;
     ctx->has_scene = true;
+    ctx->have_last = false; // (the device was synchronised above)
+    make_stream_plan(ctx);
     return PT_OK;
 }
 
@@ -2249,9 +2292,9 @@ extern "C" pt_status pt_scene_upload(pt_context *ctx, const pt_scene_desc *desc)
     std::string e = validate_desc(desc);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
     pt::BvhBuild b;
-    e = pt::build_bvh(*desc, leaf_max_for(desc), b);
+    e = pt::build_bvh(*desc, leaf_max_for(desc, &ctx->tune), b);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
-    const pt_status st = install_scene(ctx, desc, b, true);
+    const pt_status st = install_scene(ctx, desc, b);
     if (st != PT_OK) return st;
     ctx->tree = std::move(b); // kept for pt_scene_update
     return PT_OK;
@@ -2267,7 +2310,7 @@ extern "C" pt_status pt_scene_update(pt_context *ctx, const pt_scene_desc *desc)
     pt::BvhBuild b = ctx->tree; // refit a copy: a failure leaves the installed scene as it was
     e = pt::refit_bvh(*desc, b);
     if (!e.empty()) return fail(ctx, PT_ERR_INVALID, e);
-    const pt_status st = install_scene(ctx, desc, b, false);
+    const pt_status st = install_scene(ctx, desc, b);
     if (st != PT_OK) return st;
     ctx->tree = std::move(b);
     return PT_OK;
@@ -2288,22 +2331,22 @@ static size_t lds_scene_bytes(const pt_context *ctx)
     return b <= 80 * 1024 ? b : 0; // two workgroups per CU must fit in 160 KB
 }
 
-static void launch_intersect(pt_context *ctx, hipStream_t stream, const PathPlanes &cur, const uint32_t *n_ptr, size_t max_paths, bool count)
+static void launch_intersect(pt_context *ctx, const SceneDev &scene, hipStream_t stream, const PathPlanes &cur, const uint32_t *n_ptr, size_t max_paths, bool count)
 {
     const size_t lds_res = ctx->lds_scene ? lds_scene_bytes(ctx) : 0;
     if (lds_res) {
         const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min((max_paths + PT_ISECT_LDS_BLOCK - 1) / PT_ISECT_LDS_BLOCK, (size_t)ctx->n_cu * 2));
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, scene, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, true, PT_ISECT_LDS_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_ISECT_LDS_BLOCK), lds_res, stream, scene, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     } else {
         const uint32_t grid = grid_for(ctx, max_paths);
         const size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
         if (count)
-            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<true, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, scene, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
         else
-            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
+            hipLaunchKernelGGL((k_intersect<false, false, PT_BLOCK, PT_KIND_ANY>), dim3(grid), dim3(PT_BLOCK), lds, stream, scene, cur, ctx->d_hits, n_ptr, ctx->d_cnt);
     }
 }
 
@@ -2317,6 +2360,7 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
     if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR && mode != PT_TRACE_BVH_IN_SCENE) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    { const pt_status os = order_behind_last(ctx, stream); if (os != PT_OK) return os; }
     PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
     uint32_t grid = grid_for(ctx, n);
     size_t lds = (size_t)ctx->sc.stack_cap * PT_BLOCK * sizeof(uint32_t);
@@ -2327,7 +2371,7 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
     else
         hipLaunchKernelGGL(k_trace<PT_TRACE_BVH>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
     PT_HIP(ctx, hipGetLastError());
-    return PT_OK;
+    return mark_last(ctx, stream);
 }
 
 extern "C" pt_status pt_trace_rays(pt_context *ctx, const float *o, const float *d, size_t n, float t_min, float t_max,
@@ -2399,11 +2443,11 @@ struct StageTimer {
 
 
 template <bool COUNT>
-static void launch_paths(pt_context *ctx, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
+static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
                          const PassDev &ps, const SliceDev &sl, float *d_rgb_sum)
 {
     const int kind = ctx->kind;
-#define PT_LAUNCH_PATHS(L, B, S, K) hipLaunchKernelGGL((k_paths<COUNT, L, B, S, K>), dim3(grid), dim3(B), lds_bytes, stream, ctx->sc, ps, sl, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_PATHS(L, B, S, K) hipLaunchKernelGGL((k_paths<COUNT, L, B, S, K>), dim3(grid), dim3(B), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt)
 #define PT_LAUNCH_PATHS_K(L, B, S)                                               \
     do {                                                                         \
         if (kind == PT_KIND_ANY) PT_LAUNCH_PATHS(L, B, S, PT_KIND_ANY);          \
@@ -2441,58 +2485,102 @@ static const void *stream_kernel_for(bool count, int block, int kind, bool wide)
 #undef PT_STREAM_PTR
 }
 
-// The persistent-workgroup pipeline (k_paths).  Tuning knobs are read from the environment once:
-// PT_PATHS_BLOCK (256|512), PT_PATHS_LDS (0|1), PT_PATHS_PER_CU, PT_PATHS_SLICE (paths per slice), PT_PATHS_SORT (0|1).
-static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
+// Launch shape of the path kernels for the installed scene: which pipeline, workgroup size, LDS use, resident grid.
+struct PathsShape {
+    int block;
+    bool lds, sort, stream, wide;
+    size_t lds_bytes;          // k_paths: traversal stacks (+ the scene copy)
+    size_t stream_stack_bytes; // k_paths_stream: traversal stacks
+    uint32_t grid_max;         // resident workgroups
+};
+struct StreamPlan { PathsShape shape; };
+
+static PathsShape paths_shape(pt_context *ctx, uint32_t flags, bool count, bool force_stream)
 {
-    const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
-    const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
-    const bool want_lds = (pr->flags & PT_RENDER_NO_LDS_SCENE) == 0 && env_int("PT_PATHS_LDS", 1) != 0;
-    const bool sort = (pr->flags & PT_RENDER_NO_SORT) == 0 && env_int("PT_PATHS_SORT", 0) != 0; // measured slower on the spheres scene: opt-in
+    const pt_tuning &tu = ctx->tune;
     const SceneDev &sc = ctx->sc;
+    PathsShape ps;
+    const bool want_lds = (flags & PT_RENDER_NO_LDS_SCENE) == 0 && tuned(tu.lds_scene, 1) != 0;
+    ps.sort = !force_stream && (flags & PT_RENDER_NO_SORT) == 0 && tuned(tu.sort_by_material, 0) != 0; // measured slower on the spheres scene: opt-in
     const size_t scene_bytes = lds_scene_size(sc.n_nodes, sc.n_prims);
-    int block = env_int("PT_PATHS_BLOCK", 0);
+    int block = tuned(tu.block, 0);
     if (block != 256 && block != 512) {
         // LDS-resident scenes: 512 (one scene copy per 8 waves).  Scenes traversed from HBM: 256 measured best without cones;
         // with cones 512, the shape at which the compiler gets k_paths_stream's cone variant into 128 registers (4 waves per
         // SIMD instead of the 3 its 132 registers at 256 allow: 100k mixed objects 2.40 -> 2.85 Grays/s)
-        const bool fits_lds = want_lds && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024;
+        const bool fits_lds = want_lds && !force_stream && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024;
         block = fits_lds || ctx->has_cones ? 512 : 256;
     }
+    ps.block = block;
     const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
-    bool lds = want_lds && scene_bytes + stack_bytes <= 64 * 1024;
-    const size_t lds_bytes = stack_bytes + (lds ? scene_bytes : 0);
-    // scenes traversed from HBM take the streaming kernel (PT_PATHS_STREAM overrides)
-    const bool stream_kernel = !sort && env_int("PT_PATHS_STREAM", lds ? 0 : 1) != 0;
-    const bool wide = stream_kernel && sc.wide != nullptr;
+    ps.lds = want_lds && !force_stream && scene_bytes + stack_bytes <= 64 * 1024;
+    ps.lds_bytes = stack_bytes + (ps.lds ? scene_bytes : 0);
+    // scenes traversed from HBM take the streaming kernel (pt_tuning.pipeline overrides)
+    ps.stream = force_stream || (!ps.sort && tuned(tu.pipeline, ps.lds ? 0 : 1) != 0);
+    ps.wide = ps.stream && sc.wide != nullptr;
     // the wide traversal's stack; the exact replay of cone scenes walks the binary tree on the same stack
-    const size_t stream_stack_bytes = wide ? (size_t)std::max(sc.wide_stack_cap, ctx->has_cones ? sc.stack_cap : 0u) * block * 4 : stack_bytes;
-    int per_cu = env_int("PT_PATHS_PER_CU", 0);
+    ps.stream_stack_bytes = ps.wide ? (size_t)std::max(sc.wide_stack_cap, ctx->has_cones ? sc.stack_cap : 0u) * block * 4 : stack_bytes;
+    int per_cu = tuned(tu.workgroups_per_cu, 0);
     if (per_cu <= 0) {
-        const size_t static_lds = 64 + (sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
-        const size_t lds_used = (stream_kernel ? stream_stack_bytes : lds_bytes) + static_lds;
-        const int waves_per_simd = stream_kernel ? PT_STREAM_WAVES : 6; // the kernels' register budgets
+        const size_t static_lds = 64 + (ps.sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
+        const size_t lds_used = (ps.stream ? ps.stream_stack_bytes : ps.lds_bytes) + static_lds;
+        const int waves_per_simd = ps.stream ? PT_STREAM_WAVES : 6; // the kernels' register budgets
         per_cu = std::min<int>(waves_per_simd * 4 * 64 / block, (int)((160 * 1024) / std::max<size_t>(lds_used, 1)));
-        if (stream_kernel) { // what the runtime will really keep resident (its cone variants take more registers than the budget)
+        if (ps.stream) { // what the runtime will really keep resident (its cone variants take more registers than the budget)
             int fit = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, stream_kernel_for(count, block, ctx->kind, wide), block, stream_stack_bytes) == hipSuccess && fit > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, stream_kernel_for(count, block, ctx->kind, ps.wide), block, ps.stream_stack_bytes) == hipSuccess && fit > 0)
                 per_cu = std::min(per_cu, fit);
         }
         per_cu = std::max(per_cu, 1);
     }
-    const uint32_t grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
+    ps.grid_max = (uint32_t)ctx->n_cu * (uint32_t)per_cu;
+    return ps;
+}
 
-    if (stream_kernel) {
-        // One launch per pass: `spass` samples of a band of pixels.  The pass's finished radiance goes to a
-        // [samples][band pixels] buffer (1 GiB at most unless the caller fixes samples_per_pass) and k_film
-        // adds it to the film in sample order.  A frame that fits the buffer is one pass; otherwise passes of
-        // up to 256 samples go band by band, so that the samples of a pixel are traced close together in time.
+static void drop_stream_plan(pt_context *ctx)
+{
+    delete ctx->stream_plan;
+    ctx->stream_plan = nullptr;
+}
+// The streaming pipeline's shape for the installed scene, worked out where allocation and queries are allowed
+// (pt_scene_upload, pt_scene_update, pt_context_configure) so that pt_render_device_noalloc only launches.
+static void make_stream_plan(pt_context *ctx)
+{
+    drop_stream_plan(ctx);
+    if (!ctx->has_scene) return;
+    ctx->stream_plan = new StreamPlan{paths_shape(ctx, 0, false, true)};
+}
+
+// One frame through k_paths_stream + k_film.  One launch per pass: `spass` samples of a band of pixels; the pass's
+// finished radiance goes to rad ([samples][band pixels][3], room for rad_cap_paths paths) and k_film adds it to the
+// film in sample order.  A frame that fits the buffer is one pass; otherwise passes of up to 256 samples go band by
+// band, so that the samples of a pixel are traced close together in time.  Enqueues only (memsets and launches).
+static pt_status stream_passes(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, const PathsShape &sh, bool count,
+                               SceneDev scene, float *rad, uint64_t rad_cap_paths, uint32_t *ticket, Counters *cnt, struct StageTimer *tm,
+                               uint32_t *n_passes_out, unsigned long long *dbg, size_t dbg_waves);
+
+static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
+{
+    const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
+    const bool count = (pr->flags & PT_RENDER_COUNT_TESTS) != 0;
+    const PathsShape sh = paths_shape(ctx, pr->flags, count, false);
+    const int block = sh.block;
+    const bool lds = sh.lds, sort = sh.sort;
+    const size_t lds_bytes = sh.lds_bytes;
+    const uint32_t grid_max = sh.grid_max;
+    SceneDev scene = ctx->sc;
+    if (pr->flags & PT_RENDER_GEOMETRIC_CULL) { // boxes culled by exact geometry: no ray cone
+        scene.cone.kappa_max = scene.cone.kappa_min = 0.0f;
+        scene.cone.adaptive = 0;
+    }
+
+    if (sh.stream) {
+        // the pass buffer: 1 GiB at most unless the caller fixes samples_per_pass
         const uint64_t budget_paths = (1ull << 30) / 12;
-        const uint32_t tile = (uint32_t)std::max(64, env_int("PT_STREAM_TILE", 64)) & ~63u;
+        const uint32_t tile = (uint32_t)tuned(ctx->tune.stream_tile, 64);
         uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::min(pr->spp, 256u);
         spass = std::min(spass, pr->spp);
-        uint32_t band_pix = (uint32_t)std::min<uint64_t>(n_pixels, std::max<uint64_t>(tile, budget_paths / spass / tile * tile));
-        if ((uint64_t)spass * band_pix >= (1ull << 32) - (1ull << 24)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one pass"); // the path counter overshoots by up to 64 per wave
+        const uint32_t band_pix = (uint32_t)std::min<uint64_t>(n_pixels, std::max<uint64_t>(tile, budget_paths / spass / tile * tile));
         PT_HIP(ctx, hipSetDevice(ctx->device));
         const size_t need = (size_t)spass * band_pix;
         if (need > ctx->cap_prad) {
@@ -2506,16 +2594,6 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         hipEvent_t ev0 = tm.get(), ev1 = tm.get();
         PT_HIP(ctx, hipEventRecord(ev0, stream));
         PT_HIP(ctx, hipMemsetAsync(ctx->d_cnt, 0, sizeof(Counters), stream));
-        PassDev ps;
-        ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
-        ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
-        ps.max_depth = pr->max_depth;
-        const uint32_t serve_min = (uint32_t)std::min(64, std::max(1, env_int("PT_PATHS_STREAM_MIN", 32)));
-        // One kind of step per iteration (the two kinds share no code: run in the same iteration each executes with the
-        // lanes of the other masked off), leaf steps as soon as a third of the traversing lanes wait for one: 100k mixed
-        // objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for PT_STREAM_PHASE 0 (both kinds every iteration) / 2 / 3 / 4 / 6,
-        // 1M spheres 3.29 / 3.39 / 3.41 / 3.32 / 3.25 for 0 / 1 / 2 / 3 / 4.
-        const uint32_t phase_bias = (uint32_t)std::max(0, env_int("PT_STREAM_PHASE", 2));
         unsigned long long *dbg = nullptr;
         const size_t dbg_waves = (size_t)grid_max * (block / 64);
         if (kProf) { // diagnostic build: per-wave start / end clocks and step counts, reported after the call
@@ -2523,35 +2601,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
             PT_HIP(ctx, hipMemset(dbg, 0, dbg_waves * 32 + 64));
         }
         uint32_t n_passes = 0;
-        BandDev band;
-        band.tile = tile;
-        // runs of at most 256 paths: 1M spheres 3.41 -> 3.50 Grays/s, 100k mixed objects 3.56 -> 3.73 against 1024 (64 and 128 tie with 256)
-        const uint32_t run_max = (uint32_t)std::max(64, env_int("PT_STREAM_RUN", 256));
-        for (band.pix0 = 0; band.pix0 < n_pixels; band.pix0 += band_pix) {
-            band.npix = std::min(band_pix, n_pixels - band.pix0);
-            for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
-                ps.samples = std::min(spass, pr->spp - done);
-                ps.sample_base = pr->sample_offset + done;
-                const uint64_t paths = (uint64_t)ps.samples * band.npix;
-                const uint32_t grid = (uint32_t)std::min<uint64_t>(grid_max, (paths + block - 1) / block);
-                // a wave's run: long enough to keep its lanes on neighbouring pixels, short enough for 16 runs per wave
-                band.run = (uint32_t)std::min<uint64_t>(run_max, std::max<uint64_t>(64, paths / ((uint64_t)grid * (block / 64) * 16) / 64 * 64));
-                PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
-                tm.begin(1);
-                {
-                    SceneDev a_sc = ctx->sc;
-                    float *a_rad = ctx->d_prad;
-                    uint32_t *a_ticket = ctx->d_ticket;
-                    Counters *a_cnt = ctx->d_cnt;
-                    uint32_t a_serve = serve_min, a_phase = phase_bias, a_dbgw = (uint32_t)dbg_waves;
-                    void *args[] = {&a_sc, &ps, &band, &a_rad, &a_ticket, &a_cnt, &a_serve, &a_phase, &dbg, &a_dbgw};
-                    PT_HIP(ctx, hipLaunchKernel(stream_kernel_for(count, block, ctx->kind, wide), dim3(grid), dim3(block), args, stream_stack_bytes, stream));
-                }
-                tm.end();
-                hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, band.npix)), dim3(PT_BLOCK), 0, stream, ps, (const float *)ctx->d_prad, d_rgb_sum, (const uint32_t *)nullptr, ctx->d_cnt,
-                                   band.pix0, band.npix);
-            }
-        }
+        const pt_status pst = stream_passes(ctx, pr, d_rgb_sum, stream, sh, count, scene, ctx->d_prad, need, ctx->d_ticket, ctx->d_cnt, &tm, &n_passes, dbg, dbg_waves);
+        if (pst != PT_OK) return pst;
         PT_HIP(ctx, hipGetLastError());
         PT_HIP(ctx, hipEventRecord(ev1, stream));
         if (dbg) { // diagnostic build: how long the waves of the last launch lived, and what their longest rays cost
@@ -2601,6 +2652,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
             stats->exact_replays = h.exact_replays;
             stats->launches_intersect = n_passes;
             stats->passes = n_passes;
+            stats->kernel = PT_KERNEL_PATHS_STREAM;
             float ms = 0.0f;
             PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
             stats->ms_total = ms;
@@ -2621,7 +2673,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     // workgroup to balance (a slice's cost varies several-fold with what its pixels see).
     const uint64_t total_paths = (uint64_t)n_pixels * pr->spp;
     const uint32_t balanced = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(4096, total_paths / (4ull * grid_max)));
-    const uint32_t target = (uint32_t)std::max(64, env_int("PT_PATHS_SLICE", (int)balanced));
+    const uint32_t target = (uint32_t)tuned(ctx->tune.slice_paths, (int)balanced);
     uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
     spass = std::min(spass, pr->spp);
     uint32_t pix = std::max(64u, (target / spass) & ~63u);
@@ -2631,7 +2683,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     // Slices: full-sized ones while plenty of work is left, then sizes falling with what remains (what is
     // left / resident workgroups, never under a quarter of the full size), so that the workgroups finish the
     // frame together: a slice costs its workgroup 0.5-4 ms and several-fold more or less with what its pixels see.
-    const uint32_t pix_min = std::max(64u, (pix / (uint32_t)std::max(1, env_int("PT_PATHS_TAPER", 4))) & ~63u);
+    const uint32_t pix_min = std::max(64u, (pix / (uint32_t)tuned(ctx->tune.slice_taper, 4)) & ~63u);
     if (ctx->ext_key[0] != n_pixels || ctx->ext_key[1] != pix || ctx->ext_key[2] != grid_max || ctx->ext_key[3] != pix_min || !ctx->n_extents) {
         std::vector<uint2> ext;
         for (uint32_t at = 0; at < n_pixels;) {
@@ -2683,8 +2735,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (count) launch_paths<true>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
-        else launch_paths<false>(ctx, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (count) launch_paths<true>(ctx, scene, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        else launch_paths<false>(ctx, scene, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }
     PT_HIP(ctx, hipGetLastError());
@@ -2702,6 +2754,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_passes;
         stats->passes = n_passes;
+        stats->kernel = PT_KERNEL_PATHS;
         if (kProf) {
             static const char *names[6] = {"slice setup", "ray fetch / camera", "trace", "shade + emit", "bounce barriers", "film"};
             unsigned long long tot = 0;
@@ -2727,22 +2780,115 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     return PT_OK;
 }
 
-extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, void *stream_,
-                                      pt_stats *stats)
+static pt_status stream_passes(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, const PathsShape &sh, bool count,
+                               SceneDev scene, float *rad, uint64_t rad_cap_paths, uint32_t *ticket, Counters *cnt, StageTimer *tm,
+                               uint32_t *n_passes_out, unsigned long long *dbg, size_t dbg_waves)
 {
-    if (!ctx) return PT_ERR_INVALID;
+    const pt_tuning &tu = ctx->tune;
+    const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
+    const int block = sh.block;
+    const uint32_t tile = (uint32_t)tuned(tu.stream_tile, 64);
+    uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::min(pr->spp, 256u);
+    spass = std::min(spass, pr->spp);
+    if ((uint64_t)spass * tile > rad_cap_paths) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for the pass buffer");
+    const uint32_t band_pix = (uint32_t)std::min<uint64_t>(n_pixels, rad_cap_paths / spass / tile * tile);
+    if ((uint64_t)spass * band_pix >= (1ull << 32) - (1ull << 24)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one pass"); // the path counter overshoots by up to 64 per wave
+    PassDev ps;
+    ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
+    ps.k0 = (uint32_t)pr->seed; ps.k1 = (uint32_t)(pr->seed >> 32);
+    ps.max_depth = pr->max_depth;
+    const uint32_t serve_min = (uint32_t)tuned(tu.stream_serve_min, 32);
+    // One kind of step per iteration (the two kinds share no code: run in the same iteration each executes with the
+    // lanes of the other masked off), leaf steps as soon as a third of the traversing lanes wait for one: 100k mixed
+    // objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for stream_phase 0 (both kinds every iteration) / 2 / 3 / 4 / 6,
+    // 1M spheres 3.29 / 3.39 / 3.41 / 3.32 / 3.25 for 0 / 1 / 2 / 3 / 4.
+    const uint32_t phase_bias = (uint32_t)tuned(tu.stream_phase, 2);
+    // runs of at most 256 paths: 1M spheres 3.41 -> 3.50 Grays/s, 100k mixed objects 3.56 -> 3.73 against 1024 (64 and 128 tie with 256)
+    const uint32_t run_max = (uint32_t)tuned(tu.stream_run, 256);
+    const void *kernel = stream_kernel_for(count, block, ctx->kind, sh.wide);
+    uint32_t n_passes = 0;
+    BandDev band;
+    band.tile = tile;
+    for (band.pix0 = 0; band.pix0 < n_pixels; band.pix0 += band_pix) {
+        band.npix = std::min(band_pix, n_pixels - band.pix0);
+        for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
+            ps.samples = std::min(spass, pr->spp - done);
+            ps.sample_base = pr->sample_offset + done;
+            const uint64_t paths = (uint64_t)ps.samples * band.npix;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(sh.grid_max, (paths + block - 1) / block);
+            // a wave's run: long enough to keep its lanes on neighbouring pixels, short enough for 16 runs per wave
+            band.run = (uint32_t)std::min<uint64_t>(run_max, std::max<uint64_t>(64, paths / ((uint64_t)grid * (block / 64) * 16) / 64 * 64));
+            PT_HIP(ctx, hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream));
+            if (tm) tm->begin(1);
+            {
+                float *a_rad = rad;
+                uint32_t *a_ticket = ticket;
+                Counters *a_cnt = cnt;
+                uint32_t a_serve = serve_min, a_phase = phase_bias, a_dbgw = (uint32_t)dbg_waves;
+                void *args[] = {&scene, &ps, &band, &a_rad, &a_ticket, &a_cnt, &a_serve, &a_phase, &dbg, &a_dbgw};
+                PT_HIP(ctx, hipLaunchKernel(kernel, dim3(grid), dim3(block), args, sh.stream_stack_bytes, stream));
+            }
+            if (tm) tm->end();
+            hipLaunchKernelGGL(k_film, dim3(grid_for(ctx, band.npix)), dim3(PT_BLOCK), 0, stream, ps, (const float *)rad, d_rgb_sum, (const uint32_t *)nullptr, cnt,
+                               band.pix0, band.npix);
+        }
+    }
+    if (n_passes_out) *n_passes_out = n_passes;
+    return PT_OK;
+}
+
+static pt_status check_render_args(pt_context *ctx, const pt_render_params *pr, const float *d_rgb_sum)
+{
     if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
     if (!pr || !d_rgb_sum) return fail(ctx, PT_ERR_INVALID, "null parameters or output buffer");
     if (pr->width <= 0 || pr->height <= 0 || pr->spp == 0 || pr->max_depth <= 0)
         return fail(ctx, PT_ERR_INVALID, "width, height, spp and max_depth must be positive");
     if (pr->max_depth > 4096) return fail(ctx, PT_ERR_LIMIT, "max_depth above 4096");
-    const uint64_t n_pixels64 = (uint64_t)pr->width * (uint64_t)pr->height;
-    if (n_pixels64 > (1ull << 28)) return fail(ctx, PT_ERR_LIMIT, "image larger than 2^28 pixels");
+    if ((uint64_t)pr->width * (uint64_t)pr->height > (1ull << 28)) return fail(ctx, PT_ERR_LIMIT, "image larger than 2^28 pixels");
     if ((uint64_t)pr->sample_offset + pr->spp > 0xFFFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "sample index overflows 32 bits");
-    const uint32_t n_pixels = (uint32_t)n_pixels64;
+    return PT_OK;
+}
+
+// A call that enqueues work on a caller's stream and returns shares the context's workspace (counters, queues, pass
+// buffer) with the next one: each such call first makes its stream wait for the end of the previous one.
+static pt_status order_behind_last(pt_context *ctx, hipStream_t stream)
+{
+    if (ctx->have_last) PT_HIP(ctx, hipStreamWaitEvent(stream, ctx->last_done, 0));
+    return PT_OK;
+}
+static pt_status mark_last(pt_context *ctx, hipStream_t stream)
+{
+    PT_HIP(ctx, hipEventRecord(ctx->last_done, stream));
+    ctx->have_last = true;
+    return PT_OK;
+}
+
+static pt_status render_device_impl(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats);
+
+extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, void *stream_,
+                                      pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    const pt_status chk = check_render_args(ctx, pr, d_rgb_sum);
+    if (chk != PT_OK) return chk;
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    pt_status st = order_behind_last(ctx, stream);
+    if (st != PT_OK) return st;
+    st = render_device_impl(ctx, pr, d_rgb_sum, stream, stats);
+    const pt_status ms = mark_last(ctx, stream); // also after a failure part-way: what was enqueued still uses the workspace
+    return st != PT_OK ? st : ms;
+}
+
+static pt_status render_device_impl(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, hipStream_t stream, pt_stats *stats)
+{
+    const uint32_t n_pixels = (uint32_t)pr->width * (uint32_t)pr->height;
     if ((pr->flags & PT_RENDER_SPLIT_KERNELS) == 0) return render_slices(ctx, pr, d_rgb_sum, stream, stats);
+    SceneDev scene = ctx->sc;
+    if (pr->flags & PT_RENDER_GEOMETRIC_CULL) {
+        scene.cone.kappa_max = scene.cone.kappa_min = 0.0f;
+        scene.cone.adaptive = 0;
+    }
 
     // samples of every pixel in flight per pass: as many as fit the path budget
     const uint64_t budget = 1ull << 27; // 134M paths in flight = 13.4 GB of queues: tail bounces are paid once per pass
@@ -2775,15 +2921,15 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
         PT_HIP(ctx, hipMemsetAsync(ctx->d_nactive, 0, ((size_t)pr->max_depth + 1) * sizeof(uint32_t), stream));
         PathPlanes cur{ctx->d_A[0], ctx->d_B[0], ctx->d_C[0]}, nxt{ctx->d_A[1], ctx->d_B[1], ctx->d_C[1]};
         tm.begin(0);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, ctx->sc, ps, cur, ctx->d_nactive);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(PT_BLOCK), 0, stream, scene, ps, cur, ctx->d_nactive);
         tm.end();
         for (int32_t b = 0; b < pr->max_depth; ++b) {
             tm.begin(1);
-            launch_intersect(ctx, stream, cur, ctx->d_nactive + b, np, count);
+            launch_intersect(ctx, scene, stream, cur, ctx->d_nactive + b, np, count);
             tm.end();
             ++n_isect;
             tm.begin(2);
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, stream, ctx->sc, ps, cur, ctx->d_hits, nxt, ctx->d_nactive + b,
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PT_BLOCK), 0, stream, scene, ps, cur, ctx->d_hits, nxt, ctx->d_nactive + b,
                                ctx->d_nactive + b + 1, ctx->d_rad, b);
             tm.end();
             std::swap(cur, nxt);
@@ -2808,6 +2954,7 @@ extern "C" pt_status pt_render_device(pt_context *ctx, const pt_render_params *p
         stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_isect;
         stats->passes = n_passes;
+        stats->kernel = PT_KERNEL_SPLIT;
         float ms = 0.0f;
         PT_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
         stats->ms_total = ms;

@@ -54,7 +54,7 @@ def test_golden_images(ctx, name):
 # the library's pipelines and kernel variants walk the same paths: bit-identical images
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,w,h,spp,depth", [("random_spheres", 192, 108, 4, 50), ("mixed_1k", 96, 54, 6, 12), ("cornell", 64, 64, 4, 5)])
-def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
+def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth):
     ctx.upload(SCENES[name]().desc())
     base, st = ctx.render(w, h, spp, depth)
     variants = {
@@ -67,35 +67,31 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth, monkeypatch):
         img, s2 = ctx.render(w, h, spp, depth, **kw)
         assert s2["rays"] == st["rays"], tag
         assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tag
-    for env in ({"PT_PATHS_BLOCK": "256"}, {"PT_PATHS_SORT": "1"}, {"PT_PATHS_SLICE": "4096"}, {"PT_PATHS_SLICE": "1000000"},
-                # scene in HBM: the streaming kernel (default there) at several batching thresholds and
-                # workgroup sizes, and the queue-based slice kernel
-                {"hbm": "1", "PT_PATHS_STREAM_MIN": "1"}, {"hbm": "1", "PT_PATHS_STREAM_MIN": "64"},
-                {"hbm": "1", "PT_PATHS_BLOCK": "512"}, {"hbm": "1", "PT_PATHS_STREAM": "0"},
-                # node and leaf steps in every iteration / by plain majority; short runs of paths per wave
-                {"hbm": "1", "PT_STREAM_PHASE": "0"}, {"hbm": "1", "PT_STREAM_PHASE": "4"}, {"hbm": "1", "PT_STREAM_RUN": "64"},
-                {"PT_PATHS_STREAM": "1"}):
-        env = dict(env)
-        flags = api.RENDER_NO_LDS_SCENE if env.pop("hbm", None) else 0
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        img, s2 = ctx.render(w, h, spp, depth, flags=flags)
-        for k in env:
-            monkeypatch.delenv(k)
-        assert s2["rays"] == st["rays"], env
-        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), env
+    for tune in (dict(block=256), dict(sort_by_material=1), dict(slice_paths=4096), dict(slice_paths=1000000),
+                 # scene in HBM: the streaming kernel (default there) at several batching thresholds and
+                 # workgroup sizes, and the queue-based slice kernel
+                 dict(hbm=1, stream_serve_min=1), dict(hbm=1, stream_serve_min=64),
+                 dict(hbm=1, block=512), dict(hbm=1, pipeline=0),
+                 # node and leaf steps in every iteration / by plain majority; short runs of paths per wave
+                 dict(hbm=1, stream_phase=0), dict(hbm=1, stream_phase=4), dict(hbm=1, stream_run=64),
+                 dict(pipeline=1)):
+        tune = dict(tune)
+        flags = api.RENDER_NO_LDS_SCENE if tune.pop("hbm", None) else 0
+        with ctx.tuned(**tune):
+            img, s2 = ctx.render(w, h, spp, depth, flags=flags)
+        assert s2["rays"] == st["rays"], tune
+        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tune
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", [("mixed_1k", 96, 54, 4, 12), ("random_spheres", 96, 54, 2, 50)])
-def test_tree_shape_does_not_change_the_image(ctx, name, w, h, spp, depth, monkeypatch):
+def test_tree_shape_does_not_change_the_image(ctx, name, w, h, spp, depth):
     """The answer is the list scan's whatever the tree looks like: leaves of 1 to 8 objects, traversed from LDS by
     k_paths and from HBM by k_paths_stream (binary or four-wide nodes), give bit-identical images."""
     ctx.upload(SCENES[name]().desc())
     base, st = ctx.render(w, h, spp, depth)
-    for leaf in ("1", "2", "3", "8"):
-        monkeypatch.setenv("PT_LEAF_MAX", leaf)
-        ctx.upload(SCENES[name]().desc())
-        monkeypatch.delenv("PT_LEAF_MAX")
+    for leaf in (1, 2, 3, 8):
+        with ctx.tuned(leaf_max=leaf):
+            ctx.upload(SCENES[name]().desc())
         for flags in (0, api.RENDER_NO_LDS_SCENE):
             img, s2 = ctx.render(w, h, spp, depth, flags=flags)
             assert s2["rays"] == st["rays"], (leaf, flags)
@@ -334,7 +330,7 @@ def test_large_scene_render_crop(ctx, which):
 
 
 @pytest.mark.parametrize("n", [30_000, 1_000_000])
-def test_wide_and_binary_nodes_agree_bitwise(ctx, n, monkeypatch):
+def test_wide_and_binary_nodes_agree_bitwise(ctx, n):
     """The four-wide quantised tree only prunes: a field of spheres rendered through it (the default for cone-free
     scenes in HBM) and through the binary tree it was derived from gives the same image, bit for bit, over some
     million rays; so does a tree with leaves of three objects."""
@@ -343,18 +339,15 @@ def test_wide_and_binary_nodes_agree_bitwise(ctx, n, monkeypatch):
     ctx.upload(b.desc())
     base, st = ctx.render(w, h, spp, 50)
     assert st["rays"] > 1.5 * w * h * spp and st["exact_fallbacks"] == 0
-    for env in ({"PT_STREAM_WIDE": "0"}, {"PT_LEAF_MAX": "3"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx.upload(b.desc())
-        for k in env:
-            monkeypatch.delenv(k)
+    for tune in (dict(wide_nodes=0), dict(leaf_max=3)):
+        with ctx.tuned(**tune):
+            ctx.upload(b.desc())
         img, s2 = ctx.render(w, h, spp, 50)
-        assert s2["rays"] == st["rays"], env
-        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), env
+        assert s2["rays"] == st["rays"], tune
+        assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tune
 
 
-def test_path_through_a_nan_hit_is_answered_by_the_list(ctx, monkeypatch):
+def test_path_through_a_nan_hit_is_answered_by_the_list(ctx):
     """A hit at t = NaN: the reference's comparisons accept it (aarect.h:364-371 tests `t < t_min || t > t_max` and
     the bounds the same way, Q9), and from then on hittable_list::hit accepts every later entry the ray's line
     crosses, whatever its distance, until one of them brings the running t back to a number.  No box test can
@@ -383,13 +376,13 @@ def test_path_through_a_nan_hit_is_answered_by_the_list(ctx, monkeypatch):
     frac, rmse = _image_close(got, ref)
     assert frac == 0 and rmse < 2e-3 and st["rays"] == rays, (frac, rmse, st["rays"], rays)
     assert st["exact_fallbacks"] >= w * h * spp and np.isfinite(got).all()
-    monkeypatch.setenv("PT_PATHS_STREAM", "0")  # the queue-based kernel, whose traversal is bvh_nearest
-    img, s2 = ctx.render(w, h, spp, depth)
+    with ctx.tuned(pipeline=0):  # the queue-based kernel, whose traversal is bvh_nearest
+        img, s2 = ctx.render(w, h, spp, depth)
     assert s2["rays"] == rays and s2["exact_fallbacks"] >= w * h * spp and np.array_equal(img.view(np.uint32), got.view(np.uint32))
 
 
 @pytest.mark.parametrize("which", ["spheres", "mixed"])
-def test_views_along_a_coordinate_axis(ctx, which, monkeypatch):
+def test_views_along_a_coordinate_axis(ctx, which):
     """A camera looking straight down the z axis through a 0.05 degree lens: every primary ray runs almost parallel
     to two coordinate planes, where the slab test's cone widens faster than the ray advances and the planes the
     ray meets last bound t from below instead of from above.  The image must be the oracle's, and the same bit for
@@ -412,12 +405,11 @@ def test_views_along_a_coordinate_axis(ctx, which, monkeypatch):
     frac, rmse = _image_close(base, ref)
     assert frac <= 0.01 and rmse < 5e-3 and st["rays"] == rays, (frac, rmse, st["rays"], rays)
     assert (ref.sum(axis=2) > 0).mean() > 0.5
-    monkeypatch.setenv("PT_PATHS_STREAM", "0")  # the queue-based kernel on the binary tree in HBM
-    img, s2 = ctx.render(w, h, spp, depth)
-    monkeypatch.delenv("PT_PATHS_STREAM")
+    with ctx.tuned(pipeline=0):  # the queue-based kernel on the binary tree in HBM
+        img, s2 = ctx.render(w, h, spp, depth)
     assert s2["rays"] == st["rays"] and np.array_equal(img.view(np.uint32), base.view(np.uint32))
-    monkeypatch.setenv("PT_STREAM_WIDE", "1" if which == "mixed" else "0")  # the node form that is not this scene's default
-    ctx.upload(b.desc())
+    with ctx.tuned(wide_nodes=1 if which == "mixed" else 0):  # the node form that is not this scene's default
+        ctx.upload(b.desc())
     img, s2 = ctx.render(w, h, spp, depth)
     assert s2["rays"] == st["rays"] and np.array_equal(img.view(np.uint32), base.view(np.uint32))
     o = np.tile(np.array(cam[0], dtype=np.float32), (6, 1))  # and the same through pt_trace_rays
