@@ -186,6 +186,18 @@ pt_status pt_render(pt_context *ctx, const pt_render_params *params, float *rgb_
 pt_status pt_render_device(pt_context *ctx, const pt_render_params *params, float *d_rgb_sum, void *stream,
                            pt_stats *stats);
 
+/* pt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  It calls no hipMalloc / hipFree / event or stream creation
+ * and synchronises nothing: the scene must have been uploaded (and pt_context_configure called, if at all) beforehand,
+ * and its only device scratch -- the pass buffer of finished path radiance, the pass counter and the ray counters -- is
+ * a fixed PT_NOALLOC_SCRATCH_BYTES array inside the library, one copy per GPU, held until the process ends.  The frame
+ * is rendered by the streaming pipeline in passes of at most PT_NOALLOC_SCRATCH_BYTES / 12 paths; same image, bit for
+ * bit, as pt_render_device.  Limits (PT_ERR_LIMIT): width * height * spp <= 2^32 paths per call, and one 64-pixel
+ * tile of samples_per_pass samples (256 if 0) must fit the array.  Every call on a GPU shares that GPU's array: two
+ * calls that overlap in time on one GPU (different streams, different contexts) race; calls on one stream do not. */
+#define PT_NOALLOC_SCRATCH_BYTES (32u << 20)
+pt_status pt_render_device_noalloc(pt_context *ctx, const pt_render_params *params, float *d_rgb_sum, void *stream);
+
 /* main.cu:95-98 and :192-205: mean over total_spp (multiply by the reciprocal, vec3.h:136-138), sqrt
  * gamma, then int(256*clamp(c,0,0.999)) with rows written top-down from j = H-1.  Host buffers;
  * rgb_gamma (bottom-up, like fb) and rgb8 (top-down, like the BMP payload) may each be NULL. */

@@ -19,6 +19,7 @@ LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
 TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE = 0, 1, 2
 RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS, RENDER_GEOMETRIC_CULL = 1, 2, 4, 8, 16, 32
 KERNEL_NAMES = {0: "-", 1: "k_paths", 2: "k_paths_stream", 3: "k_raygen/k_intersect/k_shade/k_film"}
+NOALLOC_SCRATCH_BYTES = 32 << 20
 NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -26,7 +27,7 @@ EXPORTS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload", "pt_scene_update",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
     "pt_bvh_build_host", "pt_bvh_build_host_leaf", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
-    "pt_tuning_default", "pt_context_configure",
+    "pt_tuning_default", "pt_context_configure", "pt_render_device_noalloc",
 ]
 
 
@@ -146,6 +147,7 @@ def lib():
         L.pt_tuning_default.argtypes = [C.POINTER(PtTuning)]
         L.pt_tuning_default.restype = None
         L.pt_context_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
+        L.pt_render_device_noalloc.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -369,3 +371,7 @@ class Context:
         stats = PtStats() if want_stats else None
         self._check(lib().pt_render_device(self._h, C.byref(params), d_rgb_sum, stream, C.byref(stats) if want_stats else None))
         return stats.as_dict() if want_stats else None
+
+    def render_device_noalloc(self, params, d_rgb_sum, stream=0):
+        """pt_render_device_noalloc: launches and memsets only; scratch in the library's own per-GPU array."""
+        self._check(lib().pt_render_device_noalloc(self._h, C.byref(params), d_rgb_sum, stream))

@@ -1950,6 +1950,13 @@ struct pt_context {
 
 static int tuned(int32_t v, int dflt) { return v >= 0 ? (int)v : dflt; }
 
+// The scratch of pt_render_device_noalloc: one array per GPU inside the code object.  Host code never uses the
+// array's name as an address; g_scratch[device] holds what hipGetSymbolAddress returned with that device current.
+#define PT_SCRATCH_HEADER 1024u // the pass counter at byte 0, the Counters record at byte 256
+static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_HEADER + PT_NOALLOC_SCRATCH_BYTES];
+#define PT_MAX_DEVICES 64
+static void *g_scratch[PT_MAX_DEVICES];
+
 // Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
 // lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 1.  A leaf step
 // costs a wave the object code of every kind of object its lanes hold, once per position in the leaf that any lane
@@ -1991,6 +1998,15 @@ extern "C" pt_status pt_context_create(int device_id, pt_context **out)
     if (hipMalloc(&ctx->d_cnt, sizeof(Counters)) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
     if (hipEventCreateWithFlags(&ctx->last_done, hipEventDisableTiming) != hipSuccess) { hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
     pt_tuning_default(&ctx->tune);
+    // this GPU's copy of the no-allocation scratch array (each GPU holds its own, at its own address)
+    if (device_id < PT_MAX_DEVICES && !g_scratch[device_id]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+            hipEventDestroy(ctx->last_done); hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx;
+            return PT_ERR_DEVICE;
+        }
+        g_scratch[device_id] = p;
+    }
     *out = ctx;
     return PT_OK;
 }
@@ -2846,6 +2862,38 @@ static pt_status check_render_args(pt_context *ctx, const pt_render_params *pr, 
     if (pr->max_depth > 4096) return fail(ctx, PT_ERR_LIMIT, "max_depth above 4096");
     if ((uint64_t)pr->width * (uint64_t)pr->height > (1ull << 28)) return fail(ctx, PT_ERR_LIMIT, "image larger than 2^28 pixels");
     if ((uint64_t)pr->sample_offset + pr->spp > 0xFFFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "sample index overflows 32 bits");
+    return PT_OK;
+}
+
+// pt_render_device without allocation, queries or synchronisation: launches and memsets only, scratch in the
+// library's own per-GPU array (see `scratch` above).
+extern "C" pt_status pt_render_device_noalloc(pt_context *ctx, const pt_render_params *pr, float *d_rgb_sum, void *stream_)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    const pt_status chk = check_render_args(ctx, pr, d_rgb_sum);
+    if (chk != PT_OK) return chk;
+    if ((pr->flags & ~(uint32_t)PT_RENDER_GEOMETRIC_CULL) != 0) return fail(ctx, PT_ERR_INVALID, "pt_render_device_noalloc takes no flag but PT_RENDER_GEOMETRIC_CULL");
+    if ((uint64_t)pr->width * (uint64_t)pr->height * pr->spp > (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render_device_noalloc: more than 2^32 paths (width * height * spp) in one call");
+    if (ctx->device >= PT_MAX_DEVICES || !g_scratch[ctx->device]) return fail(ctx, PT_ERR_DEVICE, "no scratch array on this device");
+    if (!ctx->stream_plan) return fail(ctx, PT_ERR_NO_SCENE, "no launch plan: upload the scene first");
+    hipStream_t stream = (hipStream_t)stream_;
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned char *base = static_cast<unsigned char *>(g_scratch[ctx->device]); // never the array's name: that is a host-side stand-in
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(base);
+    Counters *cnt = reinterpret_cast<Counters *>(base + 256);
+    float *rad = reinterpret_cast<float *>(base + PT_SCRATCH_HEADER);
+    static_assert(256 + sizeof(Counters) <= PT_SCRATCH_HEADER, "scratch header too small");
+    // the array keeps the previous call's contents: the counters must start at zero (the pass counter is zeroed per pass)
+    PT_HIP(ctx, hipMemsetAsync(base, 0, PT_SCRATCH_HEADER, stream));
+    SceneDev scene = ctx->sc;
+    if (pr->flags & PT_RENDER_GEOMETRIC_CULL) {
+        scene.cone.kappa_max = scene.cone.kappa_min = 0.0f;
+        scene.cone.adaptive = 0;
+    }
+    const pt_status st = stream_passes(ctx, pr, d_rgb_sum, stream, ctx->stream_plan->shape, false, scene, rad, PT_NOALLOC_SCRATCH_BYTES / 12u, ticket, cnt,
+                                       nullptr, nullptr, nullptr, 0);
+    if (st != PT_OK) return st;
+    PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }
 
