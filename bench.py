@@ -3,10 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload c2]
 
-A step is one full render of the workload's image on every rank: each rank renders `spp` samples
-per pixel of its own absolute sample range (weak scaling: the image gets N*spp samples), the linear
-accumulation buffers are summed with one RCCL all-reduce, and rank 0 holds the result.  Inputs
-(scene, BVH) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+A step is one full render of the workload's image on every rank: each rank renders its own range of
+absolute sample indices (--scaling weak, the default: `spp` samples per GPU, the image gets N*spp;
+--scaling strong: the workload's spp cut into N ranges), the linear accumulation buffers are summed
+with one RCCL all-reduce (on its own stream, overlapped with the next step's render), and every rank
+holds the result.  Inputs (scene, BVH) are resident in HBM before the timed region.  Prints ONE JSON
+line on rank 0.
 """
 import argparse
 import json
@@ -23,17 +25,24 @@ import torch  # noqa: E402
 
 from pathtracer_amd import api, distributed, scenes  # noqa: E402
 
-# The benchmark configurations of BASELINE.json.  B / P: mean box and object tests per ray, measured
-# once with PT_RENDER_COUNT_TESTS on the library's tree (binned SAH, 16 bins, leaf <= 4) and frozen.
+# The benchmark configurations of BASELINE.json.  B / P (mean box and object tests per ray) come from
+# profiles/work_per_ray.json: measured once on the CPU by a plain stack traversal of a fixed reference tree (binned
+# SAH, 16 bins, leaf <= 4) over the committed ray fixtures (profiles/freeze_work_per_ray.py), and frozen.
 WORKLOADS = {
-    "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50, B=2.00, P=3.09),
-    "c2": dict(name="random-spheres (485 spheres) 1920x1080 64spp depth50", scene=scenes.random_spheres_scene, w=1920, h=1080, spp=64, depth=50, B=16.78, P=4.01),
-    "c3": dict(name="cornell box 1024x1024 1024spp depth50", scene=scenes.cornell_scene, w=1024, h=1024, spp=1024, depth=50, B=3.98, P=4.85),
-    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50, B=58.98, P=25.73),
-    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50, B=74.09, P=27.74),
+    "c1": dict(name="default scene() 400x225 16spp depth50", scene=scenes.default_scene, w=400, h=225, spp=16, depth=50),
+    "c2": dict(name="random-spheres (485 spheres) 1920x1080 64spp depth50", scene=scenes.random_spheres_scene, w=1920, h=1080, spp=64, depth=50),
+    "c3": dict(name="cornell box 1024x1024 1024spp depth50", scene=scenes.cornell_scene, w=1024, h=1024, spp=1024, depth=50),
+    "c4": dict(name="mixed 100k objects 3840x2160 256spp depth50", scene=scenes.mixed_scene, w=3840, h=2160, spp=256, depth=50),
+    "c5": dict(name="1M spheres 3840x2160 4096spp depth50", scene=scenes.sphere_slab_scene, w=3840, h=2160, spp=4096, depth=50),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
-VALU_PEAK_TFLOPS = 78.6     # fp32 vector peak WITHOUT packed v_pk_fma (half of the 157.3 spec figure)
+VALU_PEAK_TFLOPS = 157.3    # fp32 vector peak: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (v_fma_f32 issues every 2 cycles per SIMD)
+
+
+def work_per_ray(workload):
+    with open(os.path.join(ROOT, "profiles", "work_per_ray.json")) as f:
+        w = json.load(f)[workload]
+    return float(w["B"]), float(w["P"])
 
 
 def bytes_per_ray(B, P):
@@ -87,7 +96,10 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1984)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default=os.environ.get("PT_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="weak: every GPU renders the workload's spp (the image gets N x spp); strong: the workload's spp is cut into N ranges")
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
+    ap.add_argument("--cull", default="cone", choices=["cone", "geometric"], help="geometric: PT_RENDER_GEOMETRIC_CULL (labelled in the output; not the headline configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,16 +127,37 @@ def main():
     if args.spp > 0:
         spp = args.spp
         name += " [spp overridden to %d]" % spp
-    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    sample_offset, _ = distributed.weak_shard(rank, world, spp)
-    params = api.Context.params(W, H, spp, depth, seed=args.seed, sample_offset=sample_offset)
+    base_flags = api.RENDER_GEOMETRIC_CULL if args.cull == "geometric" else 0
+    if base_flags:
+        name += " [boxes culled by exact geometry]"
+    sample_offset, my_spp = distributed.shard(args.scaling, rank, world, spp)
+    spp_total = spp * world if args.scaling == "weak" else spp
+    # two accumulation buffers: the all-reduce of one step runs on its own stream while the next step renders
+    accum = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    render_stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    params = api.Context.params(W, H, my_spp, depth, seed=args.seed, sample_offset=sample_offset, flags=base_flags)
+    rendered = [torch.cuda.Event(), torch.cuda.Event()]
+    reduced = [None, None]
 
-    def step(want_stats=False, flags=0):
-        accum.zero_()
-        params.flags = flags
-        st = ctx.render_device(params, accum.data_ptr(), stream, want_stats=want_stats)
-        distributed.all_reduce_sum(accum)  # linear sums; gamma comes after (main.cu:95-98 is non-linear)
+    def step(k, want_stats=False, flags=0, ev=None):
+        buf = accum[k & 1]
+        if reduced[k & 1] is not None:
+            render_stream.wait_event(reduced[k & 1])  # the buffer's previous all-reduce has finished
+        buf.zero_()
+        params.flags = base_flags | flags
+        if ev is not None:
+            ev[0].record(render_stream)
+        st = ctx.render_device(params, buf.data_ptr(), render_stream.cuda_stream, want_stats=want_stats)
+        if ev is not None:
+            ev[1].record(render_stream)
+        if comm_stream is not None:  # linear sums; gamma comes after (main.cu:95-98 is non-linear)
+            rendered[k & 1].record(render_stream)
+            comm_stream.wait_event(rendered[k & 1])
+            with torch.cuda.stream(comm_stream):
+                distributed.all_reduce_sum(buf)
+                reduced[k & 1] = torch.cuda.Event()
+                reduced[k & 1].record(comm_stream)
         return st
 
     def sync():
@@ -132,15 +165,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    st0 = step(want_stats=True)  # ray count of this rank's sample range (deterministic per step)
-    for _ in range(max(0, args.warmup - 1)):
-        step()
+    st0 = step(0, want_stats=True)  # ray count of this rank's sample range (deterministic per step)
+    for k in range(max(0, args.warmup - 1)):
+        step(k + 1)
     sync()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k, ev=evs[k])
     sync()
     elapsed = time.perf_counter() - t0
+    ms_render = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)  # the render's launches, on the stream they run on
 
     rays_t = torch.tensor([float(st0["rays"])], dtype=torch.float64, device="cuda")
     el_t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -150,39 +185,45 @@ def main():
     rays_step = rays_t.item()
     elapsed = el_t.item()
 
-    # Dominant kernel (k_paths, the persistent-workgroup wavefront kernel): launch durations from HIP events
-    # recorded by the library on the launch stream around every k_paths launch of one more step.
-    prof = step(want_stats=True, flags=api.RENDER_STAGE_TIMES)
-    torch.cuda.synchronize()
+    # One more step with the library's own events around every launch of the dominant kernel (a cross-check of
+    # ms_render, slightly slower), and a short counting pass for the live B / P of the library's own tree.
+    prof = step(0, want_stats=True, flags=api.RENDER_STAGE_TIMES)
+    sync()
     cnt = None
-    if rank == 0 and args.workload in ("c1", "c2"):
-        cp = api.Context.params(W, H, min(spp, 4), depth, seed=args.seed, flags=api.RENDER_COUNT_TESTS)
-        accum.zero_()
-        cnt = ctx.render_device(cp, accum.data_ptr(), stream, want_stats=True)
+    if rank == 0:
+        cp = api.Context.params(W, H, min(my_spp, 2 if args.workload in ("c4", "c5") else 4), depth, seed=args.seed, flags=base_flags | api.RENDER_COUNT_TESTS)
+        accum[0].zero_()
+        cnt = ctx.render_device(cp, accum[0].data_ptr(), render_stream.cuda_stream, want_stats=True)
 
     if rank == 0:
-        bpr, fpr = bytes_per_ray(wl["B"], wl["P"]), flops_per_ray(wl["B"], wl["P"])
+        B, P = work_per_ray(args.workload)
+        bpr, fpr = bytes_per_ray(B, P), flops_per_ray(B, P)
         n_launch = max(1, prof["launches_intersect"])
-        ms_launch = prof["ms_paths"] / n_launch
-        rays_launch = prof["rays"] / n_launch
-        achieved = bpr * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kernel = api.KERNEL_NAMES.get(prof["kernel"], "?")
+        ms_launch = ms_render / n_launch
+        rays_launch = st0["rays"] / n_launch
+        tflops = fpr * rays_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
+        gbs = bpr * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(args.workload, {})
+        except Exception:
+            pmc = {}
+        traffic = pmc.get("hbm_bytes_per_ray")
         roofline = {
-            "bound": "hbm", "kernel": "k_paths" if len(builder.arrays()["prim_type"]) <= 1000 else "k_paths_stream", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "bytes_per_ray": bpr, "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
-            "valu": {"achieved_tflops": fpr * rays_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0,
-                     "peak_tflops": VALU_PEAK_TFLOPS, "peak_kind": "fp32 vector, non-packed", "flops_per_ray": fpr},
-            "note": "algorithmic bytes (32B+32P+100 per ray) over event-timed k_paths launches; for cache-resident scenes the "
-                    "figure is a rate of useful bytes, not HBM traffic (see `traffic`, from rocprofv3 PMC passes); on the "
-                    "LDS-resident scenes the kernel is VALU-issue-bound (profiles/r01_pmc_c2.json), and so is k_paths_stream on the "
-                    "large ones (profiles/r01_pmc_c5_8spp.json)",
+            "bound": "valu", "kernel": kernel, "achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
+            "traffic": traffic * rays_launch if traffic is not None else None,
+            "flops_per_ray": fpr, "bytes_per_ray": bpr, "B": B, "P": P, "work_per_ray_source": "profiles/work_per_ray.json",
+            "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
+            "ms_per_launch_library_events": prof["ms_paths"] / n_launch,
+            "hbm": {"algorithmic_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "algorithmic_frac": gbs / HBM_PEAK_GBS,
+                    "measured_GBs": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9) if traffic is not None else None,
+                    "measured_frac": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None},
+            "valu_issue": pmc.get("valu_issue"),
+            "note": "achieved = (24 B + 30 P + 60) flop per ray x rays per launch / launch time, against the fp32 vector peak; B, P frozen on a fixed "
+                    "CPU-built tree.  Node and object records come from LDS (k_paths) or L2 / Infinity Cache (k_paths_stream), so the "
+                    "algorithmic byte rate under `hbm` is not HBM traffic: measured_* is, from the rocprofv3 PMC passes in profiles/ "
+                    "(bytes per ray x this run's rays).  valu_issue: share of the vector ALUs' issue cycles in use, from the same passes.",
         }
         if cnt is not None and cnt["rays"]:
             roofline["measured_B"] = cnt["box_tests"] / cnt["rays"]
@@ -190,14 +231,19 @@ def main():
         out = {
             "metric": "Mrays/s (incl. secondary bounces)", "value": rays_step * args.steps / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "width": W, "height": H, "spp_per_gpu": my_spp, "spp_total": spp_total,
                        "max_depth": depth, "objects": int(len(builder.arrays()["prim_type"])), "rays_per_step": rays_step,
-                       "parallelism": "spp-sharded x%d + all-reduce(sum) of the fp32 accumulation buffer" % world, "seed": args.seed},
+                       "parallelism": "spp-sharded x%d (%s) + all-reduce(sum) of the fp32 accumulation buffer, overlapped with the next step's render" % (world, args.scaling),
+                       "seed": args.seed},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(builder, depth, args.seed, W, H, spp)
+            cb = cpu_baseline(builder, depth, args.seed, W, H, spp)
+            tree = cb.pop("bvh")
+            cb["sample"] += "; the same walk through a CPU-built tree (not the reference's algorithm): %.1f Mrays/s on %d cores" % (tree["value"], tree["cores"])
+            out["cpu_baseline"] = cb
+            out["cpu_baseline_tree"] = tree
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

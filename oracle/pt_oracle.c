@@ -415,6 +415,74 @@ static int hit_tree(const orc_scene *s, const orc_accel *acc, v3 o, v3 d, float 
     return have;
 }
 
+/* Work per ray on a FIXED tree, for the roofline's algorithmic bytes and flops: the same plain stack traversal as
+ * hit_tree (near child first, boxes culled by exact geometry, nearest hit shrinking the ray), counting the box tests
+ * (two per inner node visited) and the object tests it performs on every ray of a batch.  Not the reference (it has
+ * no tree) and not a checker; the counts do not depend on how any GPU kernel traverses. */
+void orc_count_tree_work(const orc_scene *s, const float *nodes, uint32_t n_nodes, const uint32_t *order, const float *o, const float *d,
+                         size_t n, float t_min, float t_max, uint64_t *box_tests, uint64_t *prim_tests)
+{
+    uint64_t nb = 0, np = 0;
+    (void)n_nodes;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : nb, np)
+    for (long long r = 0; r < (long long)n; ++r) {
+        v3 ro = vload(o + 3 * r), rd = vload(d + 3 * r);
+        int32_t stack[128];
+        int sp = 0, have = 0;
+        float best = t_max, inv[3];
+        uint32_t best_id = 0;
+        orc_hit temp;
+        memset(&temp, 0, sizeof temp);
+        for (int a = 0; a < 3; ++a) inv[a] = 1.0f / rd.e[a];
+        int32_t cur = 0;
+        for (;;) {
+            if (cur >= 0) {
+                const float *nd = nodes + (size_t)cur * 16;
+                const int32_t *ch = (const int32_t *)(nd + 12);
+                int hit[2];
+                float tn[2];
+                nb += 2;
+                for (int k = 0; k < 2; ++k) {
+                    float t0 = t_min, t1 = best;
+                    for (int a = 0; a < 3; ++a) {
+                        float x0 = (nd[4 * a + k] - ro.e[a]) * inv[a], x1 = (nd[4 * a + 2 + k] - ro.e[a]) * inv[a];
+                        if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+                        x0 -= fabsf(x0) * 1e-5f;
+                        x1 += fabsf(x1) * 1e-5f;
+                        if (x0 > t0) t0 = x0;
+                        if (x1 < t1) t1 = x1;
+                    }
+                    hit[k] = t0 <= t1;
+                    tn[k] = t0;
+                }
+                if (hit[0] && hit[1]) {
+                    int nearc = tn[1] < tn[0];
+                    if (sp < 128) stack[sp++] = ch[!nearc];
+                    cur = ch[nearc];
+                    continue;
+                }
+                if (hit[0]) { cur = ch[0]; continue; }
+                if (hit[1]) { cur = ch[1]; continue; }
+            } else {
+                uint32_t ref = (uint32_t)~cur, first = ref >> 3, count = (ref & 7u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    uint32_t i = order[first + k];
+                    np += 1;
+                    if (hit_prim(s, i, ro, rd, t_min, best, &temp) && (!have || temp.t < best || i > best_id)) {
+                        have = 1;
+                        best = temp.t;
+                        best_id = i;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    *box_tests = nb;
+    *prim_tests = np;
+}
+
 /* what ray_color queries: the reference's list scan, or the tree while orc_render_bvh runs */
 static int hit_world(const orc_scene *s, v3 o, v3 d, float t_min, float t_max, orc_hit *rec)
 {

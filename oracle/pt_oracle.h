@@ -112,6 +112,11 @@ uint64_t orc_render_region(const orc_scene *s, int width, int height, int x0, in
 uint64_t orc_render_bvh(const orc_scene *s, const float *nodes, uint32_t n_nodes, const uint32_t *order, int width, int height,
                         uint32_t sample0, uint32_t n_samples, int depth, uint64_t seed, float *rgb_sum, int threads);
 
+/* NOT the reference and not a checker: box tests and object tests a plain near-first stack traversal of the given
+ * two-wide tree performs over a batch of rays (see pt_oracle.c), for the roofline's frozen work-per-ray figures. */
+void orc_count_tree_work(const orc_scene *s, const float *nodes, uint32_t n_nodes, const uint32_t *order, const float *o, const float *d,
+                         size_t n, float t_min, float t_max, uint64_t *box_tests, uint64_t *prim_tests);
+
 /* main.cu:95-98 then :194-205: mean, sqrt gamma, 8-bit quantise, rows top-down from j = H-1. */
 void orc_finalize(const float *rgb_sum, int width, int height, uint32_t spp, float *rgb_gamma, uint8_t *rgb8);
 

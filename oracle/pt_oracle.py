@@ -163,6 +163,21 @@ class Scene:
 PHILOX_ROUNDS = 7  # ORC_PHILOX_ROUNDS: what the renderer's stream uses
 
 
+def count_tree_work(scene, nodes, order, o, d, t_min=0.001, t_max=np.finfo(np.float32).max):
+    """(box tests, object tests) of a plain stack traversal of the given tree over the rays (roofline bookkeeping)."""
+    nodes = np.ascontiguousarray(nodes)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+    nb, npr = C.c_uint64(0), C.c_uint64(0)
+    lib().orc_count_tree_work(
+        C.byref(scene.c), C.c_void_p(nodes.ctypes.data), C.c_uint32(len(nodes)), C.c_void_p(order.ctypes.data),
+        C.c_void_p(o.ctypes.data), C.c_void_p(d.ctypes.data), C.c_size_t(len(o)), C.c_float(t_min), C.c_float(t_max),
+        C.byref(nb), C.byref(npr),
+    )
+    return int(nb.value), int(npr.value)
+
+
 def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)

@@ -16,12 +16,25 @@ def weak_shard(rank, world, spp_per_rank):
 
 
 def strong_shard(rank, world, spp_total):
-    """Fixed total work: [0, spp_total) cut into `world` contiguous ranges that differ by at most one."""
+    """Fixed total work: GPU g of G renders [g*spp/G, (g+1)*spp/G): [0, spp_total) cut into `world` contiguous
+    ranges that differ by at most one sample.  Every rank must get at least one sample (pt_render_device rejects
+    an empty range)."""
     if not (0 <= rank < world) or spp_total <= 0:
         raise ValueError("bad shard request")
+    if spp_total < world:
+        raise ValueError("%d samples cannot be split over %d ranks: every rank needs at least one" % (spp_total, world))
     base, extra = divmod(spp_total, world)
     offset = rank * base + min(rank, extra)
     return offset, base + (1 if rank < extra else 0)
+
+
+def shard(mode, rank, world, spp):
+    """(first absolute sample, samples) of `rank` under "weak" (spp per rank) or "strong" (spp in total) scaling."""
+    if mode == "weak":
+        return weak_shard(rank, world, spp)
+    if mode == "strong":
+        return strong_shard(rank, world, spp)
+    raise ValueError("unknown scaling mode %r" % (mode,))
 
 
 def all_reduce_sum(t):

@@ -13,12 +13,12 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+        launches[k][r["Counter_Name"]].add((os.path.relpath(f, root).split(os.sep)[0], r["Dispatch_Id"]))  # (pass, dispatch): a counter may sit in two passes
 out = {}
 for k in sorted(agg):
     out[k] = {c: {"sum": v, "launches": len(launches[k][c]), "per_launch": v / max(1, len(launches[k][c]))} for c, v in sorted(agg[k].items())}
 summary = {"workload": workload, "kernels": out}
-ki = next((k for k in out if k.startswith("k_paths<false")), None) or next((k for k in out if k.startswith("k_intersect<false")), None)
+ki = next((k for k in out if k.startswith("k_paths_stream<false")), None) or next((k for k in out if k.startswith("k_paths<false")), None) or next((k for k in out if k.startswith("k_intersect<false")), None)
 res = {}
 if ki and "FETCH_SIZE" in out[ki] and "WRITE_SIZE" in out[ki]:
     fetch = out[ki]["FETCH_SIZE"]["per_launch"] * 1024.0

@@ -30,12 +30,21 @@ SCENES = {
 }
 
 
+# the large benchmark scenes: ray batches only (their images are checked on crops at full size by the GPU tests)
+LARGE_SCENES = {
+    "mixed_100k": scenes.mixed_scene,
+    "spheres_1m": scenes.sphere_slab_scene,
+}
+
+
 def main():
     # (b) nearest-hit batches: 4096 rays per scene (camera, two generations of scattered rays, box rays)
-    for name, f in SCENES.items():
+    for name, f in list(SCENES.items()) + list(LARGE_SCENES.items()):
         b = f()
         osc = util.oracle_scene(b)
-        o, d = util.mixed_rays(b, osc, 4096, seed=17)
+        # (the large scenes without the box rays: rays across the whole of such a scene cost several times what any
+        # ray of a render does, and these batches also fix the work per ray the benchmark's roofline is priced on)
+        o, d = util.mixed_rays(b, osc, 4096, seed=17, box=name not in LARGE_SCENES)
         h = osc.trace(o, d)
         np.savez_compressed(os.path.join(HERE, "rays_%s.npz" % name), o=o, d=d, t=h["t"], prim=h["prim"], n=h["n"],
                             front=h["front"], p=h["p"], nan_flag=h["nan_flag"])

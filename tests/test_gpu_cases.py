@@ -12,7 +12,7 @@ import pytest
 
 from pathtracer_amd import api, scenes
 from tests import util
-from tests.golden.make_golden import SCENES
+from tests.golden.make_golden import LARGE_SCENES, SCENES
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -37,6 +37,21 @@ def test_golden_ray_batches(ctx, name, mode):
     ref = {k: g[k] for k in ("t", "prim", "n", "front", "p")}
     bad = util.hits_equal(got, ref) & (g["nan_flag"] == 0)
     assert not bad.any(), (name, mode, int(bad.sum()))
+
+
+@pytest.mark.parametrize("name", list(LARGE_SCENES))
+def test_golden_ray_batches_of_the_large_scenes(ctx, name):
+    """The 100k-object and 1M-sphere scenes: camera rays and two generations of scattered rays (the batches the
+    benchmark's work per ray is frozen on), through the tree with any origin, as a render traverses it, and with boxes
+    culled by exact geometry only -- which may lose hits whose discriminant is rounding noise (see
+    test_geometric_cull_tolerance) but on these batches loses none."""
+    g = np.load(os.path.join(GOLD, "rays_%s.npz" % name))
+    ctx.upload(LARGE_SCENES[name]().desc())
+    ref = {k: g[k] for k in ("t", "prim", "n", "front", "p")}
+    for mode in (api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
+        got = ctx.trace(g["o"], g["d"], mode=mode)
+        bad = util.hits_equal(got, ref) & (g["nan_flag"] == 0)
+        assert not bad.any(), (name, mode, int(bad.sum()))
 
 
 @pytest.mark.parametrize("name", list(SCENES))

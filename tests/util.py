@@ -43,9 +43,11 @@ def box_rays(lo, hi, n, rng):
     return a, (b - a).astype(np.float32)
 
 
-def mixed_rays(builder, osc, n, seed, width=400, height=225):
+def mixed_rays(builder, osc, n, seed, width=400, height=225, box=True):
+    """n rays: camera rays, two generations of rays scattered from their hit points and (box=True) rays between random
+    points of the scene's bounds; box=False leaves a third each of the first three (what a render traces)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    n1 = n // 4
+    n1 = n // 4 if box else (n + 2) // 3
     o1, d1 = camera_rays(osc, width, height, n1, rng)
     o2, d2 = secondary_rays(osc, o1, d1, rng)
     o3, d3 = secondary_rays(osc, o2, d2, rng)
@@ -56,7 +58,7 @@ def mixed_rays(builder, osc, n, seed, width=400, height=225):
         small = ~((pt == api.SPHERE) & (np.abs(pp[:, 3]) > 100))
     c = pp[small][:, :3] if small.any() else pp[:, :3]
     lo, hi = c.min(0) - 2, c.max(0) + 2
-    n4 = max(0, n - len(o1) - len(o2) - len(o3))
+    n4 = max(0, n - len(o1) - len(o2) - len(o3)) if box else 0
     o4, d4 = box_rays(lo, hi, n4, rng)
     o = np.concatenate([o1, o2, o3, o4]).astype(np.float32)
     d = np.concatenate([d1, d2, d3, d4]).astype(np.float32)
