@@ -216,7 +216,7 @@ def main():
             "flops_per_ray": fpr, "bytes_per_ray": bpr, "B": B, "P": P, "work_per_ray_source": "profiles/work_per_ray.json",
             "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
             "ms_per_launch_library_events": prof["ms_paths"] / n_launch,
-            "hbm": {"algorithmic_GBs": gbs, "peak_GBs": HBM_PEAK_GBS, "algorithmic_frac": gbs / HBM_PEAK_GBS,
+            "hbm": {"algorithmic_GBs": gbs, "peak_GBs": HBM_PEAK_GBS,
                     "measured_GBs": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9) if traffic is not None else None,
                     "measured_frac": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None},
             "valu_issue": pmc.get("valu_issue"),

@@ -76,7 +76,7 @@ typedef struct pt_hit {
     uint32_t flags; /* bit 1: list-order dependent, replayed over the ray's candidate objects; bit 0: resolved by the full list scan */
 } pt_hit;
 
-enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1, PT_TRACE_BVH_IN_SCENE = 2 };
+enum { PT_TRACE_BVH = 0, PT_TRACE_LINEAR = 1, PT_TRACE_BVH_IN_SCENE = 2, PT_TRACE_BVH_GEOMETRIC = 3 };
 
 typedef struct pt_render_params {
     int32_t width, height;
@@ -170,7 +170,9 @@ pt_status pt_scene_update(pt_context *ctx, const pt_scene_desc *desc);
  * PT_TRACE_BVH_IN_SCENE is the traversal exactly as pt_render runs it: the caller asserts that every
  * origin lies within the scene's bounds extended to the camera (as a render's origins do), which lets
  * the traversal narrow its conservative ray cone; with origins outside, hits far from the origin
- * may be lost.  All three give the same answers where their preconditions hold. */
+ * may be lost.  All three give the same answers where their preconditions hold.
+ * PT_TRACE_BVH_GEOMETRIC is the traversal of a PT_RENDER_GEOMETRIC_CULL render (boxes culled by the objects' exact
+ * geometry, no ray cone): it may lose hits whose discriminant is rounding noise, and only those. */
 pt_status pt_trace_rays(pt_context *ctx, const float *o_xyz, const float *d_xyz, size_t n, float t_min, float t_max,
                         int mode, pt_hit *out);
 /* Same with device pointers, enqueued on `stream` (a hipStream_t; NULL = the default stream). */

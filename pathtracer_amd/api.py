@@ -16,7 +16,7 @@ STATUS_NAMES = {0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_NO_SCENE", 3: "PT_ER
 
 SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
-TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE = 0, 1, 2
+TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE, TRACE_BVH_GEOMETRIC = 0, 1, 2, 3
 RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS, RENDER_GEOMETRIC_CULL = 1, 2, 4, 8, 16, 32
 KERNEL_NAMES = {0: "-", 1: "k_paths", 2: "k_paths_stream", 3: "k_raygen/k_intersect/k_shade/k_film"}
 NOALLOC_SCRATCH_BYTES = 32 << 20

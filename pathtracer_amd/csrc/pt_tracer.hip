@@ -2373,7 +2373,7 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
     if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return PT_OK;
     if (!d_o || !d_d || !d_out) return fail(ctx, PT_ERR_INVALID, "null ray or output buffer");
-    if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR && mode != PT_TRACE_BVH_IN_SCENE) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
+    if (mode != PT_TRACE_BVH && mode != PT_TRACE_LINEAR && mode != PT_TRACE_BVH_IN_SCENE && mode != PT_TRACE_BVH_GEOMETRIC) return fail(ctx, PT_ERR_INVALID, "unknown trace mode");
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
     { const pt_status os = order_behind_last(ctx, stream); if (os != PT_OK) return os; }
@@ -2384,6 +2384,12 @@ extern "C" pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o, con
         hipLaunchKernelGGL(k_trace<PT_TRACE_LINEAR>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
     else if (mode == PT_TRACE_BVH_IN_SCENE)
         hipLaunchKernelGGL(k_trace<PT_TRACE_BVH_IN_SCENE>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
+    else if (mode == PT_TRACE_BVH_GEOMETRIC) {
+        SceneDev scene = ctx->sc; // no ray cone: boxes culled by exact geometry
+        scene.cone.kappa_max = scene.cone.kappa_min = 0.0f;
+        scene.cone.adaptive = 0;
+        hipLaunchKernelGGL(k_trace<PT_TRACE_BVH_IN_SCENE>, dim3(grid), dim3(PT_BLOCK), lds, stream, scene, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
+    }
     else
         hipLaunchKernelGGL(k_trace<PT_TRACE_BVH>, dim3(grid), dim3(PT_BLOCK), lds, stream, ctx->sc, d_o, d_d, n, t_min, t_max, d_out, ctx->d_cnt);
     PT_HIP(ctx, hipGetLastError());
