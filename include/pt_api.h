@@ -179,6 +179,22 @@ pt_status pt_trace_rays(pt_context *ctx, const float *o_xyz, const float *d_xyz,
 pt_status pt_trace_rays_device(pt_context *ctx, const float *d_o_xyz, const float *d_d_xyz, size_t n, float t_min,
                                float t_max, int mode, pt_hit *d_out, void *stream);
 
+/* material::scatter (material.h:90-99 lambertian, :155-162 metal, :223-242 dielectric, :295-299 diffuse_light) and
+ * material::emitted (material.h:45-47, :302-304) for n given hits, with the random numbers handed in instead of drawn:
+ * hit i is ray (o, d) meeting object prim[i] (list index) at distance t[i]; sphere_pt is the accepted
+ * random_in_unit_sphere point (cuda_functions.h:14-20) the lambertian and metal scatters use, xi the uniform the
+ * dielectric compares its reflectance with (material.h:235).  The device code is the render's own (the hit record is
+ * rebuilt from (object, t) as the render does it).  A parity entry like pt_trace_rays; host buffers. */
+typedef struct pt_scatter {
+    uint32_t scattered;   /* scatter()'s return value */
+    float attenuation[3];
+    float origin[3];      /* the scattered ray: the hit point ... */
+    float direction[3];   /* ... and its direction (not normalised, like the reference's) */
+    float emitted[3];
+} pt_scatter;
+pt_status pt_scatter_batch(pt_context *ctx, const float *o_xyz, const float *d_xyz, const float *t, const uint32_t *prim,
+                           const float *sphere_pt_xyz, const float *xi, size_t n, pt_scatter *out);
+
 /* render (main.cu:81-100) without its final division and gamma: adds, for every pixel, the sum of
  * ray_color over samples [sample_offset, sample_offset + spp) into rgb_sum (width*height*3 fp32, pixel
  * index j*width+i as main.cu:86).  pt_render zero-fills and writes a host buffer; pt_render_device ADDS

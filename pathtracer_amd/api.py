@@ -27,7 +27,7 @@ EXPORTS = [
     "pt_context_create", "pt_context_destroy", "pt_last_error", "pt_camera_look_at", "pt_scene_upload", "pt_scene_update",
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
     "pt_bvh_build_host", "pt_bvh_build_host_leaf", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
-    "pt_tuning_default", "pt_context_configure", "pt_render_device_noalloc",
+    "pt_tuning_default", "pt_context_configure", "pt_render_device_noalloc", "pt_scatter_batch",
 ]
 
 
@@ -88,6 +88,7 @@ class PtTuning(C.Structure):
 HIT_DTYPE = np.dtype(
     [("t", "<f4"), ("prim", "<u4"), ("n", "<f4", (3,)), ("front", "<u4"), ("p", "<f4", (3,)), ("flags", "<u4")]
 )
+SCATTER_DTYPE = np.dtype([("scattered", "<u4"), ("attenuation", "<f4", (3,)), ("origin", "<f4", (3,)), ("direction", "<f4", (3,)), ("emitted", "<f4", (3,))])
 NODE_DTYPE = np.dtype([("b", "<f4", (3, 4)), ("c", "<i4", (2,)), ("pad", "<u4", (2,))])  # b[axis] = (lo child 0, lo child 1, hi child 0, hi child 1)
 
 _lib = None
@@ -144,6 +145,7 @@ def lib():
         L.pt_bvh_wide_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
         L.pt_bvh_refit_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.pt_bvh_build_host_leaf.argtypes = [C.POINTER(PtSceneDesc), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+        L.pt_scatter_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
         L.pt_tuning_default.argtypes = [C.POINTER(PtTuning)]
         L.pt_tuning_default.restype = None
         L.pt_context_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
@@ -346,6 +348,22 @@ class Context:
             raise ValueError("origins and directions differ in length")
         out = np.zeros(len(o), dtype=HIT_DTYPE)
         self._check(lib().pt_trace_rays(self._h, o.ctypes.data, d.ctypes.data, len(o), t_min, t_max, mode, out.ctypes.data))
+        return out
+
+    def scatter(self, o, d, t, prim, sphere_pt, xi):
+        """pt_scatter_batch: material::scatter / emitted for given hits with the random numbers handed in."""
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1)
+        prim = np.ascontiguousarray(prim, dtype=np.uint32).reshape(-1)
+        sphere_pt = np.ascontiguousarray(sphere_pt, dtype=np.float32).reshape(-1, 3)
+        xi = np.ascontiguousarray(xi, dtype=np.float32).reshape(-1)
+        n = len(t)
+        if not (len(o) == len(d) == len(prim) == len(sphere_pt) == len(xi) == n):
+            raise ValueError("inputs differ in length")
+        out = np.zeros(n, dtype=SCATTER_DTYPE)
+        self._check(lib().pt_scatter_batch(self._h, o.ctypes.data, d.ctypes.data, t.ctypes.data, prim.ctypes.data, sphere_pt.ctypes.data,
+                                           xi.ctypes.data, n, out.ctypes.data))
         return out
 
     def trace_device(self, d_o, d_d, n, d_out, stream=0, t_min=0.001, t_max=FLT_MAX, mode=TRACE_BVH):

@@ -1076,6 +1076,58 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
     if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
 }
 
+// Where material::scatter's random numbers come from: the path's own stream, or values handed in (pt_scatter_batch).
+struct StreamRand {
+    Rng g;
+    __device__ __forceinline__ v3 in_unit_sphere() { return random_in_unit_sphere(g); } // cuda_functions.h:14-20
+    __device__ __forceinline__ float uniform()                                           // curand_uniform, material.h:235
+    {
+        uint32_t w4[4];
+        rng_words(g, w4);
+        return u32_to_uniform(w4[0]);
+    }
+};
+struct InjectedRand {
+    v3 sphere_pt;
+    float xi;
+    __device__ __forceinline__ v3 in_unit_sphere() { return sphere_pt; }
+    __device__ __forceinline__ float uniform() { return xi; }
+};
+
+// material::scatter (material.h:90-99 lambertian, :155-162 metal, :223-242 dielectric, :295-299 diffuse_light) for a hit
+// with face-forwarded `normal`: the reference's bool, the scattered direction and the attenuation.
+template <class Rand>
+PT_DI bool material_scatter(uint32_t mtype, const float4 &m, const Ray &r, const v3 &normal, bool front, Rand &rnd, v3 &dir, v3 &atten)
+{
+    dir = V(0.0f, 0.0f, 0.0f);
+    atten = V(0.0f, 0.0f, 0.0f);
+    if (mtype == PT_DIFFUSE_LIGHT) return false; // material.h:295-299
+    if (mtype == PT_DIELECTRIC) {                // material.h:223-242
+        float ir = m.x;
+        atten = V(1.0f, 1.0f, 1.0f);
+        float refraction_ratio = front ? (1.0f / ir) : ir;
+        v3 unit_direction = vunit(r.d);
+        float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool reflect_it = refraction_ratio * sin_theta > 1.0f;
+        if (!reflect_it) // the uniform is consumed only when refraction is possible (material.h:235)
+            reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > rnd.uniform();
+        dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
+        return true;
+    }
+    v3 rs = rnd.in_unit_sphere();
+    atten = V(m.x, m.y, m.z);
+    if (mtype == PT_LAMBERTIAN) { // material.h:90-99
+        dir = vadd(normal, vunit(rs));
+        if (vnear_zero(dir)) dir = normal;
+        return true;
+    }
+    // metal, material.h:155-162
+    v3 reflected = vreflect(vunit(r.d), normal);
+    dir = vadd(reflected, vscale(m.w, rs));
+    return vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
+}
+
 // main.cu:59-64 for one hit: emitted(), scatter(), throughput.  Returns true when the path goes on
 // (out_r, out_T are its next ray and throughput); otherwise `result` is the path's final radiance:
 // emitted() is non-zero only for diffuse_light, whose scatter() returns false (material.h:295-304),
@@ -1088,49 +1140,20 @@ PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const R
     surface_at(q, r, t, p, normal, front);
     const uint32_t mtype = (q.meta >> 3) & 3u;
     const float4 m = mats[q.meta >> 5];
-    Rng g;
-    g.pixel = pixel; g.sample = sample_abs; g.bounce = (uint32_t)bounce + 1u; g.block = 0;
-    g.k0 = ps.k0; g.k1 = ps.k1;
-    v3 dir = V(0.0f, 0.0f, 0.0f), atten = V(0.0f, 0.0f, 0.0f);
-    bool scattered = false;
+    StreamRand rnd;
+    rnd.g.pixel = pixel; rnd.g.sample = sample_abs; rnd.g.bounce = (uint32_t)bounce + 1u; rnd.g.block = 0;
+    rnd.g.k0 = ps.k0; rnd.g.k1 = ps.k1;
+    v3 dir, atten;
     result = V(0.0f, 0.0f, 0.0f);
-    if (mtype == PT_DIFFUSE_LIGHT) { // material.h:295-304
-        result = vmul(T, V(m.x, m.y, m.z));
-    } else if (mtype == PT_DIELECTRIC) { // material.h:223-242
-        float ir = m.x;
-        atten = V(1.0f, 1.0f, 1.0f);
-        float refraction_ratio = front ? (1.0f / ir) : ir;
-        v3 unit_direction = vunit(r.d);
-        float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        bool reflect_it = refraction_ratio * sin_theta > 1.0f;
-        if (!reflect_it) { // the uniform is consumed only when refraction is possible (material.h:235)
-            uint32_t w4[4];
-            rng_words(g, w4);
-            reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > u32_to_uniform(w4[0]);
-        }
-        dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
-        scattered = true;
-    } else {
-        v3 rs = random_in_unit_sphere(g);
-        if (kProf && prof) { // tries of this lane against the tries the wave had to issue
-            const uint32_t tr = g.block;
-            uint32_t mx = 1;
-            while (__ballot(tr > mx)) ++mx;
-            const unsigned long long am = __ballot(true);
-            prof->lanes[2] += tr;
-            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)am) - 1)) prof->slots[2] += 64 * mx;
-        }
-        atten = V(m.x, m.y, m.z);
-        if (mtype == PT_LAMBERTIAN) { // material.h:90-99
-            dir = vadd(normal, vunit(rs));
-            if (vnear_zero(dir)) dir = normal;
-            scattered = true;
-        } else { // metal, material.h:155-162
-            v3 reflected = vreflect(vunit(r.d), normal);
-            dir = vadd(reflected, vscale(m.w, rs));
-            scattered = vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
-        }
+    if (mtype == PT_DIFFUSE_LIGHT) result = vmul(T, V(m.x, m.y, m.z)); // material.h:302-304
+    const bool scattered = material_scatter(mtype, m, r, normal, front, rnd, dir, atten);
+    if (kProf && prof && (mtype == PT_LAMBERTIAN || mtype == PT_METAL)) { // blocks this lane drew against the blocks the wave had to issue
+        const uint32_t tr = rnd.g.block;
+        uint32_t mx = 1;
+        while (__ballot(tr > mx)) ++mx;
+        const unsigned long long am = __ballot(true);
+        prof->lanes[2] += tr;
+        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)am) - 1)) prof->slots[2] += 64 * mx;
     }
     // main.cu:64: attenuation * ray_color(scattered, depth - 1); at the last allowed bounce the next
     // ray_color call has depth <= 0 and returns black (main.cu:50-51)
@@ -1139,6 +1162,37 @@ PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const R
     out_r.d = dir;
     out_T = vmul(T, atten);
     return go_on;
+}
+
+// pt_scatter_batch: material::scatter and emitted() for given hits with the random numbers handed in.
+struct ScatterOut { uint32_t scattered; float atten[3], o[3], d[3], emitted[3]; };
+__global__ __launch_bounds__(PT_BLOCK) void k_scatter(SceneDev sc, const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ t,
+                                                      const uint32_t *__restrict__ prim, const float *__restrict__ sphere_pt, const float *__restrict__ xi, size_t n,
+                                                      ScatterOut *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * PT_BLOCK) {
+        const Ray r = load_ray_xyz(o, d, i);
+        const PrimRec *qp = sc.prims_list + prim[i];
+        PrimRec q = *qp;
+        v3 p, normal;
+        bool front;
+        surface_at(q, r, t[i], p, normal, front);
+        const uint32_t mtype = (q.meta >> 3) & 3u;
+        const float4 m = sc.mats[q.meta >> 5];
+        InjectedRand rnd;
+        rnd.sphere_pt = V(sphere_pt[3 * i], sphere_pt[3 * i + 1], sphere_pt[3 * i + 2]);
+        rnd.xi = xi[i];
+        v3 dir, atten;
+        const bool ok = material_scatter(mtype, m, r, normal, front, rnd, dir, atten);
+        ScatterOut so;
+        so.scattered = ok ? 1u : 0u;
+        so.atten[0] = atten.x; so.atten[1] = atten.y; so.atten[2] = atten.z;
+        so.o[0] = p.x; so.o[1] = p.y; so.o[2] = p.z;
+        so.d[0] = dir.x; so.d[1] = dir.y; so.d[2] = dir.z;
+        const bool light = mtype == PT_DIFFUSE_LIGHT; // material.h:45-47, :302-304
+        so.emitted[0] = light ? m.x : 0.0f; so.emitted[1] = light ? m.y : 0.0f; so.emitted[2] = light ? m.z : 0.0f;
+        out[i] = so;
+    }
 }
 
 PT_DI PrimRec load_prim(const PrimRec *arr, uint32_t slot)
@@ -2418,6 +2472,41 @@ extern "C" pt_status pt_trace_rays(pt_context *ctx, const float *o, const float 
     if (st != PT_OK) return st;
     PT_HIP(ctx, hipMemcpyAsync(out, ctx->d_rh, n * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->own_stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+    return PT_OK;
+}
+
+extern "C" pt_status pt_scatter_batch(pt_context *ctx, const float *o, const float *d, const float *t, const uint32_t *prim, const float *sphere_pt,
+                                      const float *xi, size_t n, pt_scatter *out)
+{
+    static_assert(sizeof(pt_scatter) == sizeof(ScatterOut), "pt_scatter layout");
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (!o || !d || !t || !prim || !sphere_pt || !xi || !out) return fail(ctx, PT_ERR_INVALID, "null input or output buffer");
+    for (size_t i = 0; i < n; ++i)
+        if (prim[i] >= ctx->sc.n_prims) return fail(ctx, PT_ERR_INVALID, "hit " + std::to_string(i) + " names an object that does not exist");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    // one staging buffer for the call: 3 + 3 + 1 + 1 + 3 + 1 input words and the output record per hit
+    const size_t in_words = 12, bytes = n * (in_words * 4 + sizeof(ScatterOut));
+    char *buf = nullptr;
+    PT_HIP(ctx, hipMalloc(&buf, bytes));
+    float *d_o = reinterpret_cast<float *>(buf), *d_d = d_o + 3 * n, *d_t = d_d + 3 * n;
+    uint32_t *d_prim = reinterpret_cast<uint32_t *>(d_t + n);
+    float *d_sp = reinterpret_cast<float *>(d_prim + n), *d_xi = d_sp + 3 * n;
+    ScatterOut *d_out = reinterpret_cast<ScatterOut *>(d_xi + n);
+    hipStream_t st = ctx->own_stream;
+    hipError_t e = hipSuccess;
+    auto up = [&](void *dst, const void *src, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(dst, src, b, hipMemcpyHostToDevice, st); };
+    up(d_o, o, n * 12); up(d_d, d, n * 12); up(d_t, t, n * 4); up(d_prim, prim, n * 4); up(d_sp, sphere_pt, n * 12); up(d_xi, xi, n * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_scatter, dim3(grid_for(ctx, n)), dim3(PT_BLOCK), 0, st, ctx->sc, (const float *)d_o, (const float *)d_d, (const float *)d_t,
+                           (const uint32_t *)d_prim, (const float *)d_sp, (const float *)d_xi, n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(ScatterOut), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(buf);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_DEVICE, std::string("pt_scatter_batch: ") + hipGetErrorString(e));
     return PT_OK;
 }
 

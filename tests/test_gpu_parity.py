@@ -10,6 +10,8 @@ Bars (fp32 path):
     Russian-doll of products rounds differently can flip a rejection-sampling decision further down;
     such pixels are counted, not hidden) and a relative RMSE <= 1e-3.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -210,3 +212,58 @@ def test_cone_field_exercises_the_exact_path(ctx):
     ok = ref["nan_flag"] == 0
     assert not (util.hits_equal(got, ref) & ok).any()
     assert (got["flags"] & 2).sum() > 10  # list-order dependent rays did occur and were replayed exactly
+
+
+# ------------------------------------------------------------------------------------------------
+# material::scatter with the random numbers handed in (pt_scatter_batch), bit-exact
+# ------------------------------------------------------------------------------------------------
+def _scatter_scene():
+    """The scene of tests/golden/scatter_kat.json with its unit sphere five times over, one per material, so that the
+    object index selects the material (pt_scatter_batch scatters off the hit object's own material)."""
+    b = scenes.SceneBuilder()
+    mats = [b.lambertian((0.4, 0.2, 0.1)), b.metal((0.7, 0.6, 0.5), 0.3), b.metal((0.9, 0.9, 0.9), 7.0), b.dielectric(1.5),
+            b.diffuse_light((4, 4, 4))]
+    for m in mats:
+        b.sphere((0, 0, 0), 1.0, m)
+    b.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    return b
+
+
+def _check_scatter(got, ok, atten, so, sd, emitted):
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    assert np.array_equal(got["scattered"] != 0, ok)
+    for name, want in (("attenuation", atten), ("origin", so), ("direction", sd), ("emitted", emitted)):
+        assert np.array_equal(bits(got[name]), bits(want)), name
+
+
+def test_scatter_known_answers_bit_exact(ctx):
+    """Fixture (c): lambertian, metal (fuzz 0.3 and clamped 7 -> 1), dielectric and light, both faces, absorbed and
+    scattered metal, reflection and refraction -- the GPU's material code against the committed answers."""
+    import json
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scatter_kat.json")))
+    ctx.upload(_scatter_scene().desc())
+    f = lambda k: np.array([r[k] for r in rows], dtype=np.float32)
+    got = ctx.scatter(f("o"), f("d"), f("t"), np.array([r["mat"] for r in rows], dtype=np.uint32), f("sphere_pt"), f("xi"))
+    emitted = np.array([[4, 4, 4] if r["mat"] == 4 else [0, 0, 0] for r in rows], dtype=np.float32)
+    _check_scatter(got, np.array([r["ok"] for r in rows]), f("atten"), f("so"), f("sd"), emitted)
+    assert len({(r["mat"], r["ok"]) for r in rows}) >= 6
+
+
+def test_scatter_random_hits_against_the_oracle(ctx):
+    """4000 random hits on all six kinds of object (1k mixed scene), each scattered with random injected numbers."""
+    b = scenes.mixed_scene(n=1000, seed=3, extent=20.0, n_materials=64)
+    osc = util.oracle_scene(b)
+    ctx.upload(b.desc())
+    o, d = util.mixed_rays(b, osc, 6000, seed=41)
+    h = osc.trace(o, d)
+    keep = np.flatnonzero((h["prim"] != api.NO_PRIM) & (h["nan_flag"] == 0))[:4000]
+    rng = np.random.Generator(np.random.PCG64(5))
+    sp = (rng.random((len(keep), 3), dtype=np.float32) * 2 - 1) * np.float32(0.57)
+    xi = rng.random(len(keep), dtype=np.float32)
+    a = b.arrays()
+    want = [osc.scatter(int(a["prim_material"][h["prim"][i]]), o[i], d[i], h[i], sphere_pt=sp[k], xi=float(xi[k])) for k, i in enumerate(keep)]
+    got = ctx.scatter(o[keep], d[keep], h["t"][keep], h["prim"][keep], sp, xi)
+    mt = a["mat_type"][a["prim_material"][h["prim"][keep]]]
+    emitted = np.where((mt == api.DIFFUSE_LIGHT)[:, None], a["mat_param"][a["prim_material"][h["prim"][keep]], :3], 0).astype(np.float32)
+    _check_scatter(got, np.array([w[0] for w in want]), np.array([w[1] for w in want]), np.array([w[2] for w in want]), np.array([w[3] for w in want]), emitted)
+    assert len(set(mt.tolist())) == 4 and len(set(a["prim_type"][h["prim"][keep]].tolist())) == 6
