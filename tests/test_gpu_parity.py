@@ -117,6 +117,30 @@ def test_render_full_size_crop(ctx):
     assert np.isfinite(got).all() and st["rays"] > st["primary_rays"]
 
 
+def test_cornell_full_size_and_its_eight_way_sample_split(ctx):
+    """Benchmark configuration 3 at its full size, 1024x1024 at 1024 spp, depth 50 (8 G rays): a 12x8 crop against the
+    oracle, which renders only those pixels; and the single-GPU rehearsal of its 8-GPU split: eight calls of 128 spp at
+    sample offsets 0, 128, ... (what GPU g of 8 renders) summed in float64 against the one 1024-spp call, with equal
+    ray counts (the stream is keyed by the absolute sample index)."""
+    b = scenes.cornell_scene()
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    full, st = ctx.render(1024, 1024, 1024, 50)
+    x0, y0, w, h = 640, 300, 12, 8
+    ref, _ = osc.render(1024, 1024, 1024, 50, region=(x0, y0, w, h))
+    frac, rmse = _image_close(full[y0:y0 + h, x0:x0 + w], ref)
+    assert frac <= 0.02 and rmse < 2e-3, (frac, rmse)
+    assert np.isfinite(full).all() and st["rays"] > 5 * st["primary_rays"] and st["kernel"] == 1
+    total = np.zeros(full.shape, np.float64)
+    rays = 0
+    for g in range(8):
+        part, sp = ctx.render(1024, 1024, 128, 50, sample_offset=128 * g)
+        total += part
+        rays += sp["rays"]
+    assert rays == st["rays"]
+    np.testing.assert_allclose(total, full, rtol=2e-5, atol=1e-4)
+
+
 def test_sample_shards_add_up(ctx):
     """Sample-range shards (what each GPU of a node renders) sum to the unsharded image: the stream is
     keyed by the absolute sample index, so only the fp32 association of the per-pixel sum changes."""
