@@ -216,6 +216,23 @@ pt_status pt_render_device(pt_context *ctx, const pt_render_params *params, floa
 #define PT_NOALLOC_SCRATCH_BYTES (32u << 20)
 pt_status pt_render_device_noalloc(pt_context *ctx, const pt_render_params *params, float *d_rgb_sum, void *stream);
 
+/* One image on several GPUs of a node, in one process.  Nothing in the reference corresponds (one device, main.cu:181-186).
+ * A group holds one context per GPU and one RCCL communicator over them (RCCL is loaded on first use); the scene is
+ * replicated; pt_group_render cuts params->spp into one contiguous range of absolute sample indices per GPU
+ * ([g spp / G, (g + 1) spp / G) from params->sample_offset), renders them concurrently (pt_render_device, one host
+ * thread per GPU), sums the linear accumulation buffers with one ncclAllReduce over xGMI and copies the sum to the
+ * host: feed it to pt_film_finalize with the total spp (the gamma is non-linear and must come after the reduction).
+ * The image is that of a single pt_render of the same parameters except for the fp32 association of the per-pixel sum.
+ * stats: counters summed over the GPUs, ms_total the whole call on the host's clock. */
+typedef struct pt_group pt_group;
+pt_status pt_group_create(int n_devices, const int *device_ids, pt_group **out);
+void pt_group_destroy(pt_group *g);
+int pt_group_size(const pt_group *g);
+const char *pt_group_last_error(const pt_group *g);
+pt_status pt_group_configure(pt_group *g, const pt_tuning *t);
+pt_status pt_group_scene_upload(pt_group *g, const pt_scene_desc *desc);
+pt_status pt_group_render(pt_group *g, const pt_render_params *params, float *rgb_sum_host, pt_stats *stats);
+
 /* main.cu:95-98 and :192-205: mean over total_spp (multiply by the reciprocal, vec3.h:136-138), sqrt
  * gamma, then int(256*clamp(c,0,0.999)) with rows written top-down from j = H-1.  Host buffers;
  * rgb_gamma (bottom-up, like fb) and rgb8 (top-down, like the BMP payload) may each be NULL. */

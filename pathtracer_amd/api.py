@@ -28,6 +28,7 @@ EXPORTS = [
     "pt_trace_rays", "pt_trace_rays_device", "pt_render", "pt_render_device", "pt_film_finalize",
     "pt_bvh_build_host", "pt_bvh_build_host_leaf", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
     "pt_tuning_default", "pt_context_configure", "pt_render_device_noalloc", "pt_scatter_batch",
+    "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_last_error", "pt_group_configure", "pt_group_scene_upload", "pt_group_render",
 ]
 
 
@@ -146,6 +147,15 @@ def lib():
         L.pt_bvh_refit_host.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.pt_bvh_build_host_leaf.argtypes = [C.POINTER(PtSceneDesc), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.pt_scatter_batch.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
+        L.pt_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.pt_group_destroy.argtypes = [C.c_void_p]
+        L.pt_group_destroy.restype = None
+        L.pt_group_size.argtypes = [C.c_void_p]
+        L.pt_group_last_error.argtypes = [C.c_void_p]
+        L.pt_group_last_error.restype = C.c_char_p
+        L.pt_group_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
+        L.pt_group_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
+        L.pt_group_render.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.POINTER(PtStats)]
         L.pt_tuning_default.argtypes = [C.POINTER(PtTuning)]
         L.pt_tuning_default.restype = None
         L.pt_context_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
@@ -393,3 +403,44 @@ class Context:
     def render_device_noalloc(self, params, d_rgb_sum, stream=0):
         """pt_render_device_noalloc: launches and memsets only; scratch in the library's own per-GPU array."""
         self._check(lib().pt_render_device_noalloc(self._h, C.byref(params), d_rgb_sum, stream))
+
+
+class Group:
+    """pt_group: one image on several GPUs of this node in one process (samples cut per GPU, one RCCL all-reduce)."""
+
+    def __init__(self, devices):
+        devices = list(devices)
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        st = lib().pt_group_create(len(devices), ids, C.byref(self._h))
+        if st != PT_OK:
+            raise PtError(st, "pt_group_create(%r): GPUs or RCCL not usable" % (devices,))
+
+    def close(self):
+        if self._h:
+            lib().pt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st):
+        if st != PT_OK:
+            raise PtError(st, lib().pt_group_last_error(self._h).decode())
+
+    def size(self):
+        return int(lib().pt_group_size(self._h))
+
+    def upload(self, desc):
+        self._check(lib().pt_group_scene_upload(self._h, C.byref(desc.c)))
+
+    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, flags=0):
+        """Returns (rgb_sum[h, w, 3] float32 linear sums over all GPUs' samples, stats dict)."""
+        p = Context.params(width, height, spp, max_depth, seed, sample_offset, 0, flags)
+        out = np.zeros((height, width, 3), dtype=np.float32)
+        stats = PtStats()
+        self._check(lib().pt_group_render(self._h, C.byref(p), out.ctypes.data, C.byref(stats)))
+        return out, stats.as_dict()

@@ -1,6 +1,6 @@
 // main.cpp -- the program of the reference (main.cu:106-220) on the MI355X path: reads the optional
 // scene.txt from the working directory, renders, writes image.bmp, prints the same stderr lines.
-//   pathtracer [--depth N] [--seed S] [--spp N] [--pfm file] [--scene N]   (flags are additions)
+//   pathtracer [--depth N] [--seed S] [--spp N] [--pfm file] [--scene N] [--gpus N]   (flags are additions)
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +28,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--spp")) spp_flag = atoi(val("--spp"));
         else if (!strcmp(argv[a], "--pfm")) pfm = val("--pfm");
         else if (!strcmp(argv[a], "--scene")) builtin = atoi(val("--scene"));
+        else if (!strcmp(argv[a], "--gpus")) pt_host::options().gpus = atoi(val("--gpus")); // the samples split over GPUs 0..N-1, one RCCL all-reduce
         else { std::cerr << "unknown flag " << argv[a] << "\n"; return 2; }
     }
     scene *sc = nullptr;

@@ -29,6 +29,9 @@ struct Options {
     int max_depth = 5;         // ray_color's depth argument in the reference (main.cu:93)
     uint64_t seed = 1984;      // main.cu:34
     int device = 0;
+    // > 0: render on the GPUs 0 .. gpus-1 of this node (pt_group: the samples of every pixel cut into one range per GPU,
+    // the accumulation buffers summed with one RCCL all-reduce).  The reference renders on one device (main.cu:181-186).
+    int gpus = 0;
     // The reference's file loaders parse a cone's / cylinder's `center` and then drop it, so those
     // objects always sit at the origin (cone.h:58-61,74; cylinder.h:57-60,73).  false reproduces that.
     bool honor_cone_cylinder_center = false;
@@ -132,7 +135,8 @@ public:
             d.mat_param = f.mat_param.data();
             d.camera = camera(camera_handle);
             std::memcpy(d.background, background, 12);
-            check(pt_scene_upload(ctx_, &d), "pt_scene_upload");
+            if (grp_) check_group(pt_group_scene_upload(grp_, &d), "pt_group_scene_upload");
+            else check(pt_scene_upload(ctx_, &d), "pt_scene_upload");
             uploaded_world_ = world_handle;
             uploaded_camera_ = camera_handle;
             std::memcpy(uploaded_bg_, background, 12);
@@ -144,7 +148,8 @@ public:
         p.max_depth = options.max_depth;
         p.seed = options.seed;
         sum.assign((size_t)width * height * 3, 0.0f);
-        check(pt_render(ctx_, &p, sum.data(), stats), "pt_render");
+        if (grp_) check_group(pt_group_render(grp_, &p, sum.data(), stats), "pt_group_render");
+        else check(pt_render(ctx_, &p, sum.data(), stats), "pt_render");
     }
 
     // Forgets every snapshot (the scene on the GPU stays until the next upload).
@@ -158,14 +163,26 @@ public:
     ~Session()
     {
         if (ctx_) pt_context_destroy(ctx_);
+        if (grp_) pt_group_destroy(grp_);
     }
 
 private:
     Session() {}
     void ensure_context()
     {
-        if (!ctx_ && pt_context_create(options.device, &ctx_) != PT_OK)
+        if (ctx_ || grp_) return;
+        if (options.gpus > 0) {
+            std::vector<int> ids(options.gpus);
+            for (int i = 0; i < options.gpus; ++i) ids[i] = i;
+            if (pt_group_create(options.gpus, ids.data(), &grp_) != PT_OK)
+                throw scene_error("pt_group_create failed: fewer usable GPUs than asked for, or RCCL is not loadable (this renderer has no CPU fallback)");
+        } else if (pt_context_create(options.device, &ctx_) != PT_OK) {
             throw scene_error("pt_context_create failed: no usable GPU (this renderer has no CPU fallback)");
+        }
+    }
+    void check_group(pt_status st, const char *what)
+    {
+        if (st != PT_OK) throw scene_error(std::string(what) + ": " + pt_group_last_error(grp_));
     }
     void check(pt_status st, const char *what)
     {
@@ -177,6 +194,7 @@ private:
     std::map<const void *, std::vector<int>> worlds_;
     std::map<const void *, pt_camera> cameras_;
     pt_context *ctx_ = nullptr;
+    pt_group *grp_ = nullptr;
     const void *uploaded_world_ = nullptr, *uploaded_camera_ = nullptr;
     float uploaded_bg_[3] = {0, 0, 0};
 };

@@ -1,7 +1,9 @@
 """The N>1 path on CPU: two processes over gloo shard the samples of one image exactly as bench.py's
 ranks do (pathtracer_amd.distributed), all-reduce the linear accumulation buffers, and finish the film.
 The per-rank renderer here is the CPU oracle standing in for the GPU (no GPU exists in this test); what
-is under test is the sharding, the reduction and the order 'reduce first, gamma after'."""
+is under test is the sharding (distributed.shard, both modes, the function bench.py's ranks call), the reduction and
+the order 'reduce first, gamma after'.  pt_render_device + RCCL itself runs in the GPU tests (one rank: the box has one
+GPU) and in the driver's multi-GPU bench."""
 import os
 import socket
 
@@ -29,10 +31,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         osc = util.oracle_scene(scenes.default_scene())
-        if mode == "weak":
-            off, n = distributed.weak_shard(rank, world, SPP)
-        else:
-            off, n = distributed.strong_shard(rank, world, SPP)
+        off, n = distributed.shard(mode, rank, world, SPP)  # what bench.py's ranks call
         img, rays = osc.render(W, H, n, DEPTH, sample0=off, threads=1)
         acc = torch.from_numpy(img.copy())
         distributed.all_reduce_sum(acc)

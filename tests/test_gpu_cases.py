@@ -508,3 +508,23 @@ def test_views_along_a_coordinate_axis(ctx, which):
     want = util.oracle_scene(b).trace(o, d)
     for mode in (api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
         assert not util.hits_equal(ctx.trace(o, d, mode=mode), want).any()
+
+
+def test_group_of_one_gpu_goes_through_rccl(ctx):
+    """pt_group on the GPUs this box has (one): contexts, streams, an RCCL communicator (ncclCommInitAll) and the
+    in-place ncclAllReduce of the accumulation buffer all run; with a single rank the image is pt_render's, bit for
+    bit.  More ranks cannot run here; what they compute is covered by the shard tests (sample ranges add up)."""
+    b = scenes.random_spheres_scene()
+    ctx.upload(b.desc())
+    want, st = ctx.render(320, 180, 5, 50, sample_offset=3)
+    with api.Group([0]) as g:
+        assert g.size() == 1
+        g.upload(b.desc())
+        got, sg = g.render(320, 180, 5, 50, sample_offset=3)
+        assert sg["rays"] == st["rays"] and sg["kernel"] == st["kernel"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        small, _ = g.render(64, 36, 2, 50)  # another frame size: the buffers are reallocated
+        ref, _ = ctx.render(64, 36, 2, 50)
+        assert np.array_equal(small.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(api.PtError):
+        api.Group([0, 0])  # one rank per GPU

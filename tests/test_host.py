@@ -174,6 +174,11 @@ def test_shards():
     assert max(n for _, n in cuts) - min(n for _, n in cuts) <= 1
     with pytest.raises(ValueError):
         distributed.weak_shard(4, 4, 8)
+    with pytest.raises(ValueError):  # fewer samples than ranks: a rank would get none, which pt_render_device rejects
+        distributed.strong_shard(0, 8, 7)
+    assert distributed.shard("strong", 3, 8, 64) == (24, 8) and distributed.shard("weak", 3, 8, 64) == (192, 64)
+    with pytest.raises(ValueError):
+        distributed.shard("sideways", 0, 1, 8)
 
 
 def test_random_spheres_scene_is_the_named_workload():

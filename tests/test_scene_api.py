@@ -174,3 +174,17 @@ def test_program_writes_the_image(tmp_path):
     assert np.array_equal(q[:, :, ::-1], pix)  # the BMP is the quantised frame buffer
     missing = subprocess.run([exe, "--spp", "1"], cwd=tmp_path / "..", capture_output=True, text=True, timeout=120)  # no scene.txt: default scene
     assert missing.returncode == 0 and "Rendering a 1200x902 image" in missing.stderr
+
+
+@pytest.mark.gpu
+def test_program_on_a_group_of_gpus(tmp_path):
+    """`pathtracer --gpus 1`: the same program through pt_group (contexts per GPU, RCCL all-reduce of the
+    accumulation buffers); with one GPU the frame buffer is the single-context program's, byte for byte."""
+    exe = os.path.join(HOST, "pathtracer")
+    (tmp_path / "scene.txt").write_text(open(SAMPLE).read())
+    a = subprocess.run([exe, "--pfm", "one.pfm"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    b = subprocess.run([exe, "--pfm", "group.pfm", "--gpus", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert (tmp_path / "one.pfm").read_bytes() == (tmp_path / "group.pfm").read_bytes()
+    many = subprocess.run([exe, "--gpus", "64", "--spp", "64"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert many.returncode == 99 and "pt_group_create failed" in many.stderr  # more GPUs than the box has: a clean error
