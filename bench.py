@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--scaling", default=os.environ.get("PT_BENCH_SCALING", "weak"), choices=["weak", "strong"],
                     help="weak: every GPU renders the workload's spp (the image gets N x spp); strong: the workload's spp is cut into N ranges")
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
+    ap.add_argument("--force-collective", action="store_true", help="with one GPU: still create the process group (one rank) and run the all-reduce on its stream, to rehearse the N > 1 code path")
     ap.add_argument("--cull", default="cone", choices=["cone", "geometric"], help="geometric: PT_RENDER_GEOMETRIC_CULL (labelled in the output; not the headline configuration)")
     args = ap.parse_args()
 
@@ -113,9 +114,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
 
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
@@ -135,7 +141,7 @@ def main():
     # two accumulation buffers: the all-reduce of one step runs on its own stream while the next step renders
     accum = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     render_stream = torch.cuda.current_stream()
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    comm_stream = torch.cuda.Stream() if dist is not None else None
     params = api.Context.params(W, H, my_spp, depth, seed=args.seed, sample_offset=sample_offset, flags=base_flags)
     rendered = [torch.cuda.Event(), torch.cuda.Event()]
     reduced = [None, None]

@@ -38,9 +38,9 @@ def shard(mode, rank, world, spp):
 
 
 def all_reduce_sum(t):
-    """Sums a linear accumulation tensor over all ranks in place (no-op for a single process)."""
+    """Sums a linear accumulation tensor over all ranks in place (no-op without a process group)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
