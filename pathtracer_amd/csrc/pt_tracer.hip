@@ -1597,6 +1597,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
     // pixels, whose rays meet the same part of the tree: with lanes filled from one pass-wide sequence
     // instead, the 1M-sphere scene ran 25 % slower.
     uint32_t dbg_iter = 0, dbg_steps = 0, dbg_maxsteps = 0, dbg_serves = 0; // diagnostic build: loop iterations, steps of the current / longest ray, serves
+    ProfLanes prof; // diagnostic build: issues and active lanes of 0 four-wide steps, 1 two-child steps, 2 leaf steps, 3 shading, 4 new paths
     const uint32_t npix = band.npix;
     const uint32_t n_paths = npix * ps.samples;
     const uint32_t tile_paths = band.tile * ps.samples;
@@ -1660,6 +1661,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                 h.t = nh.best_t;
                 h.slot = nh.best_slot;
                 bool scan_list = false;
+                bool fresh = false; // this lane leaves the serve with a new ray (scattered, or the first of a new path)
                 if (to_shade) {
                     bool need_exact = by_list;
                     settle_parked<CONES>(nh, need_exact);
@@ -1688,6 +1690,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                     }
                 }
                 if (to_shade) { // main.cu:54-64 for the ray just traced
+                    prof.tick(3);
                     bool go_on = false;
                     v3 result;
                     if (h.slot == PT_NO_PRIM) {
@@ -1702,7 +1705,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                             r = nray;
                             T = nT;
                             bounce++;
-                            start_ray();
+                            if (CONES) start_ray(); else fresh = true;
                         }
                     }
                     if (!go_on) {
@@ -1729,17 +1732,21 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         }
                         const uint32_t k = lane_prefix(m);
                         if (need && k < run_end - run_next) {
+                            prof.tick(4);
                             uint32_t s, pl;
                             path_of(run_next + k, pl, s);
                             lid = s * npix + pl;
                             r = camera_ray(sc.cam, ps, band.pix0 + pl, ps.sample_base + s); // main.cu:88-92
                             T = V(1.0f, 1.0f, 1.0f);
                             bounce = 0;
-                            start_ray();
+                            if (CONES) start_ray(); else fresh = true;
                         }
                         run_next += min((uint32_t)__popcll(m), run_end - run_next); // (lanes left without a path come back at once)
                     }
                 }
+                // once for both kinds of new ray: the slab constants are a sixth of a serve's instructions (1M spheres +4.6 %).  The
+                // cone variant has no register for the flag across the serve and keeps the two sites (0.7 % slower merged).
+                if (!CONES && fresh) start_ray();
                 if (__ballot(lid != PT_NO_PRIM) == 0ull) break; // no path left in this wave, none to take
                 continue;
             }
@@ -1759,6 +1766,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                                           : reinterpret_cast<const float4 *>(sc.prims + (ref >> 3));
                 const float4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3]; // (the object array is padded by one record)
                 if (WIDE && inner) {
+                    prof.tick(0);
                     // pt::WideNode: origin, step exponents, the four children's planes as bytes per axis, their references
                     const uint32_t eb = __float_as_uint(w0.w);
                     const float stx = __uint_as_float((eb & 0xFFu) << 23), sty = __uint_as_float((eb & 0xFF00u) << 15), stz = __uint_as_float((eb & 0xFF0000u) << 7);
@@ -1799,10 +1807,16 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                             if (steep_rejects(sb, pfx, pfy, pfz, tf, br.eps)) key[k] = 0xFFFFFFFFu;
                         }
                     }
-                    // nearest first: a five-exchange sorting network on the keys
-                    auto order2 = [](uint32_t &a, uint32_t &b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; };
-                    order2(key[0], key[1]); order2(key[2], key[3]); order2(key[0], key[2]); order2(key[1], key[3]); order2(key[1], key[2]);
-                    auto ref_of = [&](uint32_t kk) { const uint32_t i = kk & 3u; return i == 0 ? cr[0] : i == 1 ? cr[1] : i == 2 ? cr[2] : cr[3]; };
+                    // nearest first: a five-exchange sorting network on the keys, the children's references moving with them
+                    // (selecting a reference by a sorted key's slot bits afterwards costs more than the ten selects here)
+                    auto order2 = [](uint32_t &a, uint32_t &b, int32_t &ra, int32_t &rb) {
+                        const bool s = b < a;
+                        const uint32_t lo = s ? b : a, hi = s ? a : b;
+                        const int32_t rlo = s ? rb : ra, rhi = s ? ra : rb;
+                        a = lo; b = hi; ra = rlo; rb = rhi;
+                    };
+                    order2(key[0], key[1], cr[0], cr[1]); order2(key[2], key[3], cr[2], cr[3]); order2(key[0], key[2], cr[0], cr[2]);
+                    order2(key[1], key[3], cr[1], cr[3]); order2(key[1], key[2], cr[1], cr[2]);
                     const uint32_t n_hit = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
                     if (n_hit == 0) {
                         node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
@@ -1811,13 +1825,14 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                             by_list = true; // the stack cannot take them (deeper than 31 entries): the list answers this ray
                             node = PT_TRAVERSAL_DONE;
                         } else {
-                            if (n_hit > 3) stack[(sp++) * BLOCK] = (uint32_t)ref_of(key[3]);
-                            if (n_hit > 2) stack[(sp++) * BLOCK] = (uint32_t)ref_of(key[2]);
-                            if (n_hit > 1) stack[(sp++) * BLOCK] = (uint32_t)ref_of(key[1]);
-                            node = ref_of(key[0]);
+                            if (n_hit > 3) stack[(sp++) * BLOCK] = (uint32_t)cr[3];
+                            if (n_hit > 2) stack[(sp++) * BLOCK] = (uint32_t)cr[2];
+                            if (n_hit > 1) stack[(sp++) * BLOCK] = (uint32_t)cr[1];
+                            node = cr[0];
                         }
                     }
                 } else if (inner) {
+                    prof.tick(1);
                     float2 nx, ny, nz, fx, fy, fz;
                     int32_t c0, c1;
                     planes_of_record(w0, w1, w2, w3, br, nx, ny, nz, fx, fy, fz, c0, c1);
@@ -1845,6 +1860,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
                     }
                 } else {
+                    prof.tick(2);
                     const uint32_t first = ref >> 3, left = (ref & 7u) + 1u;
                     PrimRec q;
                     q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
@@ -1906,6 +1922,14 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
             dbg[2 * nw + 2 * w] = ((unsigned long long)dbg_iter << 32) | dbg_serves;
             dbg[2 * nw + 2 * w + 1] = ((unsigned long long)mx << 32) | (uint32_t)rays;
         }
+    }
+    if (kProf) {
+        for (int k = 0; k < 5; ++k) {
+            const unsigned long long a = wave_sum_u32(prof.lanes[k]), b2 = wave_sum_u32(prof.slots[k]);
+            if (lane == 0) { atomicAdd(&cnt->lanes[k], a); atomicAdd(&cnt->slots[k], b2); }
+        }
+        const unsigned long long it = wave_sum_u32(lane == 0 ? dbg_iter : 0u), sv = wave_sum_u32(lane == 0 ? dbg_serves : 0u);
+        if (lane == 0) { atomicAdd(&cnt->sect[0], it); atomicAdd(&cnt->sect[1], sv); }
     }
     rays = wave_sum_u32((uint32_t)rays);
     if (lane == 0 && rays) atomicAdd(&cnt->rays, rays);
@@ -2755,6 +2779,14 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
             Counters h;
             PT_HIP(ctx, hipMemcpyAsync(&h, ctx->d_cnt, sizeof h, hipMemcpyDeviceToHost, stream));
             PT_HIP(ctx, hipStreamSynchronize(stream));
+            if (kProf) { // how often each part of the loop was issued by a wave, and with how many of its lanes
+                static const char *const part[5] = {"four-wide step", "two-child step", "leaf step", "shading", "new path"};
+                const double rays = (double)std::max<unsigned long long>(h.rays, 1ull);
+                fprintf(stderr, "[prof] k_paths_stream: %.3f loop iterations and %.3f serves per 64 rays\n", 64.0 * (double)h.sect[0] / rays, 64.0 * (double)h.sect[1] / rays);
+                for (int k = 0; k < 5; ++k)
+                    fprintf(stderr, "[prof]   %-15s %8.3f issues per 64 rays, %7.3f per ray by its own lane, lanes active %5.1f %%\n", part[k], (double)h.slots[k] / rays,
+                            (double)h.lanes[k] / rays, 100.0 * (double)h.lanes[k] / (double)std::max(h.slots[k], 1ull));
+            }
             stats->rays = h.rays;
             stats->primary_rays = (uint64_t)pr->spp * n_pixels;
             stats->box_tests = h.box_tests;
