@@ -318,11 +318,13 @@ PT_DI bool hit_cone_ordered(const ConeRoots &cr, float t_min, float t_max, float
 
 // Point, outward normal, face flag: sphere.h:103-107, aarect.h:356-360 (+2 variants),
 // cone.h:125-136, cylinder.h:119-127, hittable.h:29-32.
+// (SPH: the scene holds spheres only, the caller knows)
+template <bool SPH = false>
 PT_DI void surface_at(const PrimRec &q, const Ray &r, float t, v3 &p, v3 &normal, bool &front)
 {
     p = ray_at(r.o, r.d, t);
     v3 outward;
-    switch (q.meta & 7u) {
+    switch (SPH ? (uint32_t)PT_SPHERE : q.meta & 7u) {
     case PT_SPHERE: outward = vdiv(vsub(p, V(q.p[0], q.p[1], q.p[2])), q.p[3]); break;
     case PT_XY_RECT: outward = V(0.0f, 0.0f, 1.0f); break;
     case PT_XZ_RECT: outward = V(0.0f, 1.0f, 0.0f); break;

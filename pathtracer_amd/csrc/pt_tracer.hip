@@ -1126,12 +1126,13 @@ PT_DI bool material_scatter(uint32_t mtype, const float4 &m, const Ray &r, const
 // (out_r, out_T are its next ray and throughput); otherwise `result` is the path's final radiance:
 // emitted() is non-zero only for diffuse_light, whose scatter() returns false (material.h:295-304),
 // so a path's radiance is known exactly when it ends and is T * (emit | background | black).
+template <bool SPH = false>
 PT_DI bool shade_hit(const float4 *__restrict__ mats, const PassDev &ps, const Ray &r, v3 T, uint32_t pixel, uint32_t sample_abs,
                      int32_t bounce, const PrimRec &q, float t, Ray &out_r, v3 &out_T, v3 &result, ProfLanes *prof = nullptr)
 {
     v3 p, normal;
     bool front;
-    surface_at(q, r, t, p, normal, front);
+    surface_at<SPH>(q, r, t, p, normal, front);
     const uint32_t mtype = (q.meta >> 3) & 3u;
     const float4 m = mats[q.meta >> 5];
     StreamRand rnd;
@@ -1367,12 +1368,21 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                     if (h.slot == PT_NO_PRIM) {
                         result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
                     } else {
-                        PrimRec q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
+                        PrimRec q;
+                        if (LDS && KIND == PT_KIND_SPHERES) { // the copy in LDS (a sphere-only scene never resolves a hit by the list)
+                            float4 w0, w1;
+                            lsrc.prim(h.slot, w0, w1);
+                            q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                            q.meta = __float_as_uint(w1.z);
+                            q.id = __float_as_uint(w1.w);
+                        } else {
+                            q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
+                        }
                         uint32_t s = lid / npix, pl = lid - s * npix;
                         Ray nr;
                         v3 nT;
                         if (kProf) prof.tick(3);
-                        survive = shade_hit(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, b, q, h.t, nr, nT, result, &prof);
+                        survive = shade_hit<KIND == PT_KIND_SPHERES>(sc.mats, ps, r, T, pix0 + pl, ps.sample_base + s, b, q, h.t, nr, nT, result, &prof);
                         if (survive) {
                             oA = make_float4(nr.o.x, nr.o.y, nr.o.z, __uint_as_float(lid));
                             oB = make_float4(nr.d.x, nr.d.y, nr.d.z, nT.x);
@@ -1694,7 +1704,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         const uint32_t s = lid / npix, pl = lid - s * npix;
                         Ray nray;
                         v3 nT;
-                        go_on = shade_hit(sc.mats, ps, r, T, band.pix0 + pl, ps.sample_base + s, bounce, q, h.t, nray, nT, result);
+                        go_on = shade_hit<SPH>(sc.mats, ps, r, T, band.pix0 + pl, ps.sample_base + s, bounce, q, h.t, nray, nT, result);
                         if (go_on) {
                             r = nray;
                             T = nT;
