@@ -1632,7 +1632,8 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
             br = make_box_ray(r, ray_kappa(sc.cone, r.o));
             nh.reset(t_max);
             by_list = false;
-            sp = 0;
+            stack[0] = (uint32_t)PT_TRAVERSAL_DONE; // the bottom entry says "done": a pop needs no test for an empty stack
+            sp = 1;
             node = 0; // root
             rays++;
             // A ray with a NaN or infinite component (the reference accepts hits whose t is NaN, and the
@@ -1823,7 +1824,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                     order2(key[1], key[3], cr[1], cr[3]); order2(key[1], key[2], cr[1], cr[2]);
                     const uint32_t n_hit = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
                     if (n_hit == 0) {
-                        node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
+                        node = (int32_t)stack[(--sp) * BLOCK];
                     } else {
                         if (sp + n_hit - 1u > sc.wide_stack_cap) {
                             by_list = true; // the stack cannot take them (deeper than 31 entries): the list answers this ray
@@ -1851,18 +1852,13 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         if (steep_rejects(sb, fx.x, fy.x, fz.x, tf0, br.eps)) h0 = false;
                         if (steep_rejects(sb, fx.y, fy.y, fz.y, tf1, br.eps)) h1 = false;
                     }
-                    if (h0 && h1) {
-                        const bool swap = tn1 < tn0;
-                        if (sp < sc.stack_cap) stack[(sp++) * BLOCK] = (uint32_t)(swap ? c0 : c1);
-                        else by_list = true;
-                        node = swap ? c1 : c0;
-                    } else if (h0) {
-                        node = c0;
-                    } else if (h1) {
-                        node = c1;
-                    } else {
-                        node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
-                    }
+                    // the next child by selects, one masked store, one masked load (as in bvh_nearest; the stack holds the
+                    // tree's depth + 2 entries, one per level of a descent and the bottom one)
+                    const bool both = h0 && h1;
+                    const bool pick1 = (both && tn1 < tn0) || (!h0 && h1);
+                    node = pick1 ? c1 : c0;
+                    if (both) stack[(sp++) * BLOCK] = (uint32_t)(pick1 ? c0 : c1);
+                    if (!(h0 || h1)) node = (int32_t)stack[(--sp) * BLOCK];
                 } else {
                     prof.tick(2);
                     const uint32_t first = ref >> 3, left = (ref & 7u) + 1u;
@@ -1911,7 +1907,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         by_list = true;
                         node = PT_TRAVERSAL_DONE;
                     } else if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
-                    else node = sp == 0 ? PT_TRAVERSAL_DONE : (int32_t)stack[(--sp) * BLOCK];
+                    else node = (int32_t)stack[(--sp) * BLOCK];
                 }
             }
         }
@@ -2357,7 +2353,7 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.wide = n_wide;
     // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
     // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
-    sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 1u) : 0u;
+    sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 2u) : 0u; // (with the bottom entry; 31 x 256 lanes x 4 B lets five workgroups share a CU's LDS)
     ctx->wide_depth = want_wide ? wb.max_depth : 0u;
     sc.nodes = ctx->d_nodes;
     sc.prims = ctx->d_prims;
