@@ -1797,7 +1797,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                         asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(fz), "v"(nh.best_t));
                         asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(m));
                         const bool hit = tn <= tf + br.eps && cr[k] != pt::kWideAbsent;
-                        key[k] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : 0xFFFFFFFFu; // tn >= t_min > 0: its bits order as it does
+                        key[k] = ((__float_as_uint(tn) & ~3u) | (uint32_t)k) | (hit ? 0u : 0xFFFFFFFFu); // tn >= t_min > 0: its bits order as it does
                     }
                     if (COUNT) nb += 4;
                     if (br.afx == 0.0f || br.afy == 0.0f || br.afz == 0.0f) { // a steep axis (rare): the bound its open far slot leaves out
