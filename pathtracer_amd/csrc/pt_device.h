@@ -325,7 +325,7 @@ PT_DI void surface_at(const PrimRec &q, const Ray &r, float t, v3 &p, v3 &normal
     p = ray_at(r.o, r.d, t);
     v3 outward;
     switch (SPH ? (uint32_t)PT_SPHERE : q.meta & 7u) {
-    case PT_SPHERE: outward = vdiv(vsub(p, V(q.p[0], q.p[1], q.p[2])), q.p[3]); break;
+    case PT_SPHERE: outward = vscale(q.p[4] /* 1 / radius, as the scene's records hold it */, vsub(p, V(q.p[0], q.p[1], q.p[2]))); break;
     case PT_XY_RECT: outward = V(0.0f, 0.0f, 1.0f); break;
     case PT_XZ_RECT: outward = V(0.0f, 1.0f, 0.0f); break;
     case PT_YZ_RECT: outward = V(1.0f, 0.0f, 0.0f); break;

@@ -2213,6 +2213,7 @@ static void make_records(const pt_scene_desc &d, const std::vector<uint32_t> &or
     for (uint32_t i = 0; i < d.n_prims; ++i) {
         PrimRec &q = list[i];
         for (int k = 0; k < 6; ++k) q.p[k] = d.prim_param[(size_t)i * 6 + k];
+        if (d.prim_type[i] == PT_SPHERE) q.p[4] = 1.0f / q.p[3]; // the factor of sphere.h:105's (p - center) / radius (vec3.h:272-274), once per sphere instead of once per hit
         uint32_t m = d.prim_material[i];
         q.meta = (uint32_t)d.prim_type[i] | ((uint32_t)d.mat_type[m] << 3) | (m << 5);
         q.id = i;
