@@ -1096,17 +1096,23 @@ PT_DI bool material_scatter(uint32_t mtype, const float4 &m, const Ray &r, const
     dir = V(0.0f, 0.0f, 0.0f);
     atten = V(0.0f, 0.0f, 0.0f);
     if (mtype == PT_DIFFUSE_LIGHT) return false; // material.h:295-299
-    if (mtype == PT_DIELECTRIC) {                // material.h:223-242
+    // unit_vector(r_in.direction()) and its reflection, material.h:156 and :228 / :238: worked out once for the lanes of both
+    // materials (a wave that shades a metal hit nearly always shades a glass hit too, and would run the code twice)
+    v3 unit_direction = V(0.0f, 0.0f, 0.0f), reflected = V(0.0f, 0.0f, 0.0f);
+    if (mtype != PT_LAMBERTIAN) {
+        unit_direction = vunit(r.d);
+        reflected = vreflect(unit_direction, normal);
+    }
+    if (mtype == PT_DIELECTRIC) { // material.h:223-242
         float ir = m.x;
         atten = V(1.0f, 1.0f, 1.0f);
         float refraction_ratio = front ? (1.0f / ir) : ir;
-        v3 unit_direction = vunit(r.d);
         float cos_theta = fminf(vdot(vneg(unit_direction), normal), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool reflect_it = refraction_ratio * sin_theta > 1.0f;
         if (!reflect_it) // the uniform is consumed only when refraction is possible (material.h:235)
             reflect_it = reflectance_schlick(cos_theta, refraction_ratio) > rnd.uniform();
-        dir = reflect_it ? vreflect(unit_direction, normal) : vrefract(unit_direction, normal, refraction_ratio);
+        dir = reflect_it ? reflected : vrefract(unit_direction, normal, refraction_ratio);
         return true;
     }
     v3 rs = rnd.in_unit_sphere();
@@ -1117,7 +1123,6 @@ PT_DI bool material_scatter(uint32_t mtype, const float4 &m, const Ray &r, const
         return true;
     }
     // metal, material.h:155-162
-    v3 reflected = vreflect(vunit(r.d), normal);
     dir = vadd(reflected, vscale(m.w, rs));
     return vdot(dir, normal) > 0.0f; // absorbed paths return emitted() = black (main.cu:61-62)
 }
