@@ -106,6 +106,30 @@ int pth_render(int width, int height, int spp, int max_depth, float *fb, unsigne
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
+// Two scenes alive at once: the second one's world must flatten to what it flattens to alone (its own materials, numbered
+// from 0).  Returns 1 if so, 0 if not, -1 on an error.
+int pth_two_scenes_alive()
+{
+    pth_close();
+    try {
+        scene *alone = new scene(1);
+        const pt_host::Flat ref = pt_host::Session::get().flatten(alone->world->d_this);
+        delete alone;
+        pt_host::Session::get().reset();
+        scene *first = new scene();
+        scene *second = new scene(1);
+        const pt_host::Flat got = pt_host::Session::get().flatten(second->world->d_this);
+        const pt_host::Flat one = pt_host::Session::get().flatten(first->world->d_this);
+        const bool same = got.mat_type == ref.mat_type && got.mat_param == ref.mat_param && got.prim_material == ref.prim_material &&
+                          got.prim_type == ref.prim_type && got.prim_param == ref.prim_param;
+        (void)one;
+        delete second;
+        delete first;
+        pt_host::Session::get().reset();
+        return same ? 1 : 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 // ordering contract: an object created before its material must be refused, not crash
 int pth_ordering_violation()
 {

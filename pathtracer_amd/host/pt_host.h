@@ -100,14 +100,22 @@ public:
         auto it = worlds_.find(world_handle);
         if (it == worlds_.end()) throw scene_error("unknown world handle: call create_hittable_on_gpu() and copy_list_to_gpu() first");
         Flat f;
-        // every material created so far, in creation order: a positional `material = N` in scene.txt
-        // refers to that order (scene.h:216-237), and the object snapshots hold those indices
-        f.mat_type = mat_tag_;
-        f.mat_param = mat_par_;
+        // The world's materials: the run of the registry from the first to the last one its objects use, in creation order
+        // (a scene creates its materials together, scene.h:216-237), renumbered from 0.  A second scene alive in the same
+        // process therefore neither sees nor uploads the first one's materials.
+        uint32_t lo = UINT32_MAX, hi = 0;
+        for (int s : it->second) {
+            lo = obj_mat_[s] < lo ? obj_mat_[s] : lo;
+            hi = obj_mat_[s] > hi ? obj_mat_[s] : hi;
+        }
+        if (lo <= hi) {
+            f.mat_type.assign(mat_tag_.begin() + lo, mat_tag_.begin() + hi + 1);
+            f.mat_param.assign(mat_par_.begin() + 4 * (size_t)lo, mat_par_.begin() + 4 * ((size_t)hi + 1));
+        }
         for (int s : it->second) {
             f.prim_type.push_back(obj_tag_[s]);
             f.prim_param.insert(f.prim_param.end(), obj_par_.begin() + 6 * (size_t)s, obj_par_.begin() + 6 * (size_t)s + 6);
-            f.prim_material.push_back(obj_mat_[s]);
+            f.prim_material.push_back(obj_mat_[s] - lo);
         }
         return f;
     }

@@ -107,6 +107,11 @@ def test_ordering_contract_is_checked(H):
     assert H.pth_ordering_violation() == 1  # object created before its material: refused, where the reference dereferences NULL
 
 
+def test_two_scenes_alive_do_not_share_materials(H):
+    """A world flattens to its own materials, numbered from 0, whatever other scenes the process holds."""
+    assert H.pth_two_scenes_alive() == 1, H.pth_error().decode()
+
+
 def test_reference_style_scene_definition_compiles_without_cuda(tmp_path):
     """A scene definition written the reference's way (constructors, create_*_on_gpu, public fields, d_this)
     compiles against pathtracer_amd/host with plain g++ and no GPU toolkit."""
