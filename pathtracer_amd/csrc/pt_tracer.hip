@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
                     } else {
                         PrimRec q;
-                        if (LDS && KIND == PT_KIND_SPHERES) { // the copy in LDS (a sphere-only scene never resolves a hit by the list)
+                        if (LDS && (KIND == PT_KIND_SPHERES || (h.slot & 0x80000000u) == 0)) { // the copy in LDS, unless the list resolved the hit (never in a sphere-only scene)
                             float4 w0, w1;
                             lsrc.prim(h.slot, w0, w1);
                             q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
