@@ -1760,6 +1760,19 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                 if (__ballot(lid != PT_NO_PRIM) == 0ull) break; // no path left in this wave, none to take
                 continue;
             }
+            // Traversal steps follow each other in a loop of their own until a serve is due (the same moment the test at the
+            // top of the outer loop would find): the outer loop merges the state a serve writes -- ray, slab constants,
+            // nearest hit, parked cone -- with the state a step writes, a dozen register moves per iteration, and the
+            // two-child step is short (100k mixed objects +15 %).  The four-wide step is long and its variant sits at the
+            // register limit of five waves per SIMD: there the inner loop loses 1-8 % and is left out.
+            constexpr bool STEP_LOOP = !WIDE;
+#pragma nounroll
+            for (bool first_step = true;; first_step = false) {
+            if (!first_step) {
+                if (!STEP_LOOP) break;
+                const unsigned long long rest = __ballot(node == PT_TRAVERSAL_DONE && (!exhausted || lid != PT_NO_PRIM));
+                if ((uint32_t)__popcll(rest) >= serve_min || __ballot(node != PT_TRAVERSAL_DONE) == 0ull) break;
+            }
             // One kind of step per iteration, the one more lanes are waiting for: the two kinds share no code, and
             // run in the same iteration each would execute with the lanes of the other masked off.
             bool my_turn = true;
@@ -1914,6 +1927,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                     } else if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
                     else node = (int32_t)stack[(--sp) * BLOCK];
                 }
+            }
             }
         }
     }
