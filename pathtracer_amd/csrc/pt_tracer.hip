@@ -1763,9 +1763,9 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
             // Traversal steps follow each other in a loop of their own until a serve is due (the same moment the test at the
             // top of the outer loop would find): the outer loop merges the state a serve writes -- ray, slab constants,
             // nearest hit, parked cone -- with the state a step writes, a dozen register moves per iteration, and the
-            // two-child step is short (100k mixed objects +15 %).  The four-wide step is long and its variant sits at the
-            // register limit of five waves per SIMD: there the inner loop loses 1-8 % and is left out.
-            constexpr bool STEP_LOOP = !WIDE;
+            // two-child step is short (100k mixed objects +15 %; their four-wide step +10 %).  The cone-free four-wide
+            // variant sits at the register limit of five waves per SIMD: there the inner loop spills, loses 1-8 % and is left out.
+            constexpr bool STEP_LOOP = !WIDE || CONES;
 #pragma nounroll
             for (bool first_step = true;; first_step = false) {
             if (!first_step) {
@@ -2335,10 +2335,10 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
         only_spheres &= desc->prim_type[i] == PT_SPHERE;
     }
     // Scenes too large for LDS are rendered from the four-wide form of the tree (k_paths_stream): 1.8 times fewer
-    // node fetches per ray, 1M spheres 2.82 -> 3.47 Grays/s.  Not for scenes with cones, whose kernel variant
-    // has no registers to spare for the four-child step (100k mixed objects: 3.68 -> 2.03).  pt_tuning.wide_nodes overrides.
+    // node fetches per ray, 1M spheres 2.82 -> 3.47 Grays/s; with cones (whose kernel variant waits on those fetches
+    // with four waves per SIMD) 100k mixed objects 4.54 -> 5.02.  pt_tuning.wide_nodes overrides.
     pt::WideBuild wb;
-    const bool want_wide = nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, any_cone ? 0 : 1) != 0;
+    const bool want_wide = nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, 1) != 0;
     if (want_wide) pt::make_wide(b, wb);
 
     BvhNode *n_nodes = nullptr;

@@ -23,14 +23,15 @@ def fields(v):
     return {} if v == "-" else {k: int(x) for k, x in (kv.split("=") for kv in v.split(","))}
 
 
+reupload = any(k in ("leaf_max", "wide_nodes") for v in variants for k in fields(v))
 res = {v: [] for v in variants}
 img = {}
 for r in range(rounds + 1):
     for v in variants:
         f = fields(v)
         with ctx.tuned(**f):
-            if any(k in ("leaf_max", "wide_nodes") for k in f):
-                ctx.upload(desc)  # these take effect when a scene is installed
+            if reupload:
+                ctx.upload(desc)  # leaf_max and wide_nodes take effect when a scene is installed
             acc.zero_()
             torch.cuda.synchronize()
             st = ctx.render_device(p, acc.data_ptr(), 0, want_stats=True)
