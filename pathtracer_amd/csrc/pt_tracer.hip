@@ -1766,6 +1766,16 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
             // two-child step is short (100k mixed objects +15 %; their four-wide step +10 %).  The cone-free four-wide
             // variant sits at the register limit of five waves per SIMD: there the inner loop spills, loses 1-8 % and is left out.
             constexpr bool STEP_LOOP = !WIDE || CONES;
+            // The record a lane needs next is asked for as soon as its reference is known -- at the end of the step that
+            // produced it, before the votes and tests of the next iteration -- and waits in pw0..pw3 for the lane's turn.
+            constexpr bool PREFETCH = STEP_LOOP; // (100k mixed objects +6.6 %)
+            float4 pw0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pw1 = pw0, pw2 = pw0, pw3 = pw0;
+            auto fetch = [&]() {
+                const float4 *rec = node >= 0 ? (WIDE ? sc.wide + 4 * (size_t)node : reinterpret_cast<const float4 *>(sc.nodes + node))
+                                              : reinterpret_cast<const float4 *>(sc.prims + ((uint32_t)~node >> 3));
+                pw0 = rec[0]; pw1 = rec[1]; pw2 = rec[2]; pw3 = rec[3]; // (the object array is padded by one record)
+            };
+            if (PREFETCH && node != PT_TRAVERSAL_DONE) fetch();
 #pragma nounroll
             for (bool first_step = true;; first_step = false) {
             if (!first_step) {
@@ -1785,9 +1795,8 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                 if (kProf) dbg_steps++;
                 const bool inner = node >= 0;
                 const uint32_t ref = (uint32_t)~node; // leaf: (first object << 3) | (objects left - 1)
-                const float4 *rec = inner ? (WIDE ? sc.wide + 4 * (size_t)node : reinterpret_cast<const float4 *>(sc.nodes + node))
-                                          : reinterpret_cast<const float4 *>(sc.prims + (ref >> 3));
-                const float4 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3]; // (the object array is padded by one record)
+                if (!PREFETCH) fetch();
+                const float4 w0 = pw0, w1 = pw1, w2 = pw2, w3 = pw3;
                 if (WIDE && inner) {
                     prof.tick(0);
                     // pt::WideNode: origin, step exponents, the four children's planes as bytes per axis, their references
@@ -1927,6 +1936,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                     } else if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
                     else node = (int32_t)stack[(--sp) * BLOCK];
                 }
+                if (PREFETCH && node != PT_TRAVERSAL_DONE) fetch();
             }
             }
         }
