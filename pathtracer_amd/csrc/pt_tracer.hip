@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
 // in small groups costs nothing that matters.)
 // ---------------------------------------------------------------------------------------------
 #ifndef PT_STREAM_WAVES
-#define PT_STREAM_WAVES 5
+#define PT_STREAM_WAVES 4 // waves per SIMD of every k_paths_stream variant (117-128 VGPRs)
 #endif
 // One pass of k_paths_stream: `samples` samples (PassDev) of the pixels [pix0, pix0 + npix).
 struct BandDev {
@@ -1585,7 +1585,7 @@ struct BandDev {
 };
 
 template <bool COUNT, int BLOCK, int KIND, bool WIDE>
-__global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
+__global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDev sc, PassDev ps, BandDev band, float *__restrict__ rad /* [samples][band pixels][3] of this pass */,
                                                                            uint32_t *__restrict__ ticket, Counters *cnt,
                                                                            uint32_t serve_min /* lanes waiting for shading or a new path before they are served */, uint32_t phase_bias /* 0: node and leaf steps in every iteration */,
                                                                            unsigned long long *dbg = nullptr /* diagnostic build only */, uint32_t dbg_waves = 0)
@@ -1762,24 +1762,22 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
             }
             // Traversal steps follow each other in a loop of their own until a serve is due (the same moment the test at the
             // top of the outer loop would find): the outer loop merges the state a serve writes -- ray, slab constants,
-            // nearest hit, parked cone -- with the state a step writes, a dozen register moves per iteration, and the
-            // two-child step is short (100k mixed objects +15 %; their four-wide step +10 %).  The cone-free four-wide
-            // variant sits at the register limit of five waves per SIMD: there the inner loop spills, loses 1-8 % and is left out.
-            constexpr bool STEP_LOOP = !WIDE || CONES;
+            // nearest hit, parked cone -- with the state a step writes, a dozen register moves per iteration that the inner
+            // loop does not pay (100k mixed objects: 31 % fewer vector instructions, +15 %; 1M spheres: 10 % fewer, +2 %
+            // at four waves per SIMD, where the loop fits the registers without spilling).
             // The record a lane needs next is asked for as soon as its reference is known -- at the end of the step that
-            // produced it, before the votes and tests of the next iteration -- and waits in pw0..pw3 for the lane's turn.
-            constexpr bool PREFETCH = STEP_LOOP; // (100k mixed objects +6.6 %)
+            // produced it, before the votes and tests of the next iteration -- and waits in pw0..pw3 for the lane's turn
+            // (100k mixed objects +6.6 %).
             float4 pw0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pw1 = pw0, pw2 = pw0, pw3 = pw0;
             auto fetch = [&]() {
                 const float4 *rec = node >= 0 ? (WIDE ? sc.wide + 4 * (size_t)node : reinterpret_cast<const float4 *>(sc.nodes + node))
                                               : reinterpret_cast<const float4 *>(sc.prims + ((uint32_t)~node >> 3));
                 pw0 = rec[0]; pw1 = rec[1]; pw2 = rec[2]; pw3 = rec[3]; // (the object array is padded by one record)
             };
-            if (PREFETCH && node != PT_TRAVERSAL_DONE) fetch();
+            if (node != PT_TRAVERSAL_DONE) fetch();
 #pragma nounroll
             for (bool first_step = true;; first_step = false) {
             if (!first_step) {
-                if (!STEP_LOOP) break;
                 const unsigned long long rest = __ballot(node == PT_TRAVERSAL_DONE && (!exhausted || lid != PT_NO_PRIM));
                 if ((uint32_t)__popcll(rest) >= serve_min || __ballot(node != PT_TRAVERSAL_DONE) == 0ull) break;
             }
@@ -1795,7 +1793,6 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                 if (kProf) dbg_steps++;
                 const bool inner = node >= 0;
                 const uint32_t ref = (uint32_t)~node; // leaf: (first object << 3) | (objects left - 1)
-                if (!PREFETCH) fetch();
                 const float4 w0 = pw0, w1 = pw1, w2 = pw2, w3 = pw3;
                 if (WIDE && inner) {
                     prof.tick(0);
@@ -1936,7 +1933,7 @@ __global__ __launch_bounds__(BLOCK, KIND == PT_KIND_ANY ? PT_STREAM_WAVES - 1 : 
                     } else if (left > 2) node = ~(int32_t)(((first + 2u) << 3) | (left - 3u)); // the rest of the leaf
                     else node = (int32_t)stack[(--sp) * BLOCK];
                 }
-                if (PREFETCH && node != PT_TRAVERSAL_DONE) fetch();
+                if (node != PT_TRAVERSAL_DONE) fetch();
             }
             }
         }
@@ -2972,10 +2969,10 @@ static pt_status stream_passes(pt_context *ctx, const pt_render_params *pr, floa
     ps.max_depth = pr->max_depth;
     const uint32_t serve_min = (uint32_t)tuned(tu.stream_serve_min, 32);
     // One kind of step per iteration (the two kinds share no code: run in the same iteration each executes with the
-    // lanes of the other masked off), leaf steps as soon as a third of the traversing lanes wait for one: 100k mixed
-    // objects 2.57 / 3.55 / 3.48 / 3.45 / 3.41 Grays/s for stream_phase 0 (both kinds every iteration) / 2 / 3 / 4 / 6,
-    // 1M spheres 3.29 / 3.39 / 3.41 / 3.32 / 3.25 for 0 / 1 / 2 / 3 / 4.
-    const uint32_t phase_bias = (uint32_t)tuned(tu.stream_phase, 2);
+    // lanes of the other masked off), leaf steps as soon as a fifth of the traversing lanes wait for one: with the step
+    // loop, 1M spheres 4.52 / 4.44 / 4.33 / 4.19 Grays/s for stream_phase 1 / 2 / 3 / 4, 100k mixed objects 5.03 / 5.01 /
+    // 4.98 / 4.91 and 4.81 for 0 (both kinds in every iteration).
+    const uint32_t phase_bias = (uint32_t)tuned(tu.stream_phase, 1);
     // runs of at most 256 paths: 1M spheres 3.41 -> 3.50 Grays/s, 100k mixed objects 3.56 -> 3.73 against 1024 (64 and 128 tie with 256)
     const uint32_t run_max = (uint32_t)tuned(tu.stream_run, 256);
     const void *kernel = stream_kernel_for(count, block, ctx->kind, sh.wide);
