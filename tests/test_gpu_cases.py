@@ -111,6 +111,11 @@ def test_tree_shape_does_not_change_the_image(ctx, name, w, h, spp, depth):
             img, s2 = ctx.render(w, h, spp, depth, flags=flags)
             assert s2["rays"] == st["rays"], (leaf, flags)
             assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), (leaf, flags)
+    with ctx.tuned(wide_nodes=0):  # k_paths_stream's two-child step (four-wide nodes are the default from HBM)
+        ctx.upload(SCENES[name]().desc())
+    img, s2 = ctx.render(w, h, spp, depth, flags=api.RENDER_NO_LDS_SCENE)
+    assert s2["rays"] == st["rays"]
+    assert np.array_equal(img.view(np.uint32), base.view(np.uint32))
 
 
 def test_render_is_deterministic_and_seeded(ctx):
