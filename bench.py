@@ -122,7 +122,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL launches the reduction on the process group's own stream: ask for a high-priority one
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+        except Exception:  # an older binding: the default stream priority then
+            opts = None
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
     wl = WORKLOADS[args.workload]
     builder = wl["scene"]()
@@ -141,7 +148,9 @@ def main():
     # two accumulation buffers: the all-reduce of one step runs on its own stream while the next step renders
     accum = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     render_stream = torch.cuda.current_stream()
-    comm_stream = torch.cuda.Stream() if dist is not None else None
+    # high priority: when a render ends, the all-reduce of its buffer and the next render both become ready, and the
+    # reduction's few workgroups should get their slots before the persistent render kernel takes every CU
+    comm_stream = torch.cuda.Stream(priority=-1) if dist is not None else None
     params = api.Context.params(W, H, my_spp, depth, seed=args.seed, sample_offset=sample_offset, flags=base_flags)
     rendered = [torch.cuda.Event(), torch.cuda.Event()]
     reduced = [None, None]
