@@ -134,7 +134,7 @@ typedef struct pt_tuning {
     int32_t slice_taper;       /* 1..64: the last slices of a frame shrink to 1/taper of a full one */
     int32_t sort_by_material;  /* 0 / 1: block-local material sort before shading in k_paths */
     int32_t stream_serve_min;  /* 1..64 lanes waiting before k_paths_stream shades them */
-    int32_t stream_phase;      /* 0..16: 0 both kinds of step per iteration, n: a leaf step once n/4 of the traversing lanes wait for one */
+    int32_t stream_phase;      /* 0..16: 0 both kinds of step per iteration; n: a leaf step once the lanes waiting for one outnumber n/4 of those at inner nodes (default 1) */
     int32_t stream_tile;       /* 64..4096, a multiple of 64: pixels per tile of k_paths_stream's path numbering */
     int32_t stream_run;        /* 64..65536: consecutive paths a wave takes at a time */
 } pt_tuning;
