@@ -137,6 +137,7 @@ typedef struct pt_tuning {
     int32_t stream_phase;      /* 0..16: 0 both kinds of step per iteration; n: a leaf step once the lanes waiting for one outnumber n/4 of those at inner nodes (default 1) */
     int32_t stream_tile;       /* 64..4096, a multiple of 64: pixels per tile of k_paths_stream's path numbering */
     int32_t stream_run;        /* 64..65536: consecutive paths a wave takes at a time */
+    int32_t split_queue;       /* 0 / 1: k_paths on an LDS-resident scene of spheres queues the rays that head up (camera's up vector) apart from the others; the library's choice: scenes with a non-black background */
 } pt_tuning;
 void pt_tuning_default(pt_tuning *t); /* every field negative */
 /* PT_ERR_INVALID (and no change) if a non-negative field is out of its range. */

@@ -78,7 +78,7 @@ class PtStats(C.Structure):
 
 
 TUNING_FIELDS = ("leaf_max", "wide_nodes", "pipeline", "lds_scene", "block", "workgroups_per_cu", "slice_paths", "slice_taper",
-                 "sort_by_material", "stream_serve_min", "stream_phase", "stream_tile", "stream_run")
+                 "sort_by_material", "stream_serve_min", "stream_phase", "stream_tile", "stream_run", "split_queue")
 
 
 class PtTuning(C.Structure):

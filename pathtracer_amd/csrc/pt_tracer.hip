@@ -1290,12 +1290,12 @@ struct SliceDev {
     uint32_t *ticket;
 };
 
-template <bool COUNT, bool LDS, int BLOCK, bool SORT, int KIND>
+template <bool COUNT, bool LDS, int BLOCK, bool SORT, int KIND, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
     constexpr int WAVES = BLOCK / 64;
     extern __shared__ float4 s_mem[];
-    __shared__ uint32_t s_slice, s_out[2];
+    __shared__ uint32_t s_slice, s_out[4]; // [parity][0: queued from the front, 1: from the back (SPLIT)]
     __shared__ uint2 s_hit[SORT ? BLOCK : 1];       // (t bits, slot) of the chunk's rays, by thread
     __shared__ uint16_t s_perm[SORT ? BLOCK : 1];   // thread whose ray is shaded at each sorted position
     __shared__ uint16_t s_bin[SORT ? 4 * WAVES : 1]; // per (class, wave) counts, then exclusive offsets
@@ -1351,10 +1351,10 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         const uint2 extent = sl.extents[slice]; // first pixel, pixels
         const uint32_t pix0 = extent.x;
         const uint32_t npix = extent.y;
-        uint32_t in_count = npix * ps.samples;
+        uint32_t in_count = npix * ps.samples, in_lo = in_count;
         uint32_t cur = 0;
         for (int32_t b = 0; b < ps.max_depth && in_count > 0; ++b) {
-            if (threadIdx.x == 0) s_out[b & 1] = 0;
+            if (threadIdx.x == 0) s_out[2 * (b & 1)] = s_out[2 * (b & 1) + 1] = 0;
             __syncthreads();
             mark(4);
             const float4 *inA = qA + cur * cap, *inB = qB + cur * cap;
@@ -1400,11 +1400,33 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                         rad[3 * lid + 2] = result.z;
                     }
                 }
+                if (SPLIT) {
+                    // Survivors are queued from both ends of the next queue: rays that head up (by the camera's up vector; in an
+                    // open scene most of them leave it after a few node visits) from the back, the others from the front.  A
+                    // wave of the next bounce then holds rays of one kind, but for the one chunk where the two runs meet, and
+                    // its lanes finish their traversals closer together.
+                    const bool up = oB.x * sc.cam.v[0] + oB.y * sc.cam.v[1] + oB.z * sc.cam.v[2] > 0.0f;
+                    const unsigned long long m0 = __ballot(survive && !up), m1 = __ballot(survive && up);
+                    if (m0 | m1) {
+                        const unsigned long long mine = up ? m1 : m0;
+                        const uint32_t pre = lane_prefix(mine);
+                        uint32_t pos0 = 0;
+                        if (survive && pre == 0) pos0 = atomicAdd(&s_out[2 * (b & 1) + (up ? 1 : 0)], (uint32_t)__popcll(mine));
+                        const uint32_t p0 = __shfl(pos0, m0 ? __ffsll((long long)m0) - 1 : 0, 64), p1 = __shfl(pos0, m1 ? __ffsll((long long)m1) - 1 : 0, 64);
+                        if (survive) {
+                            const uint32_t at = up ? cap - 1u - (p1 + pre) : p0 + pre;
+                            outA[at] = oA;
+                            outB[at] = oB;
+                            outC[at] = oC;
+                        }
+                    }
+                    return;
+                }
                 const unsigned long long mask = __ballot(survive);
                 if (mask) {
                     const uint32_t pre = lane_prefix(mask);
                     uint32_t pos0 = 0;
-                    if (survive && pre == 0) pos0 = atomicAdd(&s_out[b & 1], (uint32_t)__popcll(mask));
+                    if (survive && pre == 0) pos0 = atomicAdd(&s_out[2 * (b & 1)], (uint32_t)__popcll(mask));
                     pos0 = __shfl(pos0, __ffsll((long long)mask) - 1, 64);
                     if (survive) {
                         outA[pos0 + pre] = oA;
@@ -1444,8 +1466,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
                     h.t = 0.0f;
                     h.slot = PT_NO_PRIM;
                     if (i < in_count) {
-                        float4 A = inA[i], B = inB[i];
-                        float2 C = inC[i];
+                        const uint32_t qi = SPLIT && i >= in_lo ? cap - 1u - (i - in_lo) : i; // (the rays queued from the back)
+                        float4 A = inA[qi], B = inB[qi];
+                        float2 C = inC[qi];
                         lid = __float_as_uint(A.w);
                         r.o = V(A.x, A.y, A.z);
                         r.d = V(B.x, B.y, B.z);
@@ -1517,7 +1540,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
             __syncthreads();
             mark(4);
             if (threadIdx.x == 0) rays += in_count;
-            in_count = s_out[b & 1];
+            in_lo = s_out[2 * (b & 1)];
+            in_count = in_lo + (SPLIT ? s_out[2 * (b & 1) + 1] : 0u);
             cur ^= 1u;
         }
         // film: col += ray_color(...) in sample order (main.cu:93) for the slice's pixels
@@ -2145,6 +2169,7 @@ extern "C" pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t)
     else if (!in(t->stream_phase, 0, 16)) bad = "stream_phase (0..16)";
     else if (!(t->stream_tile < 0 || (t->stream_tile >= 64 && t->stream_tile <= 4096 && t->stream_tile % 64 == 0))) bad = "stream_tile (64..4096, a multiple of 64)";
     else if (!in(t->stream_run, 64, 65536)) bad = "stream_run (64..65536)";
+    else if (!in(t->split_queue, 0, 1)) bad = "split_queue (0, 1)";
     if (bad) return fail(ctx, PT_ERR_INVALID, std::string("pt_tuning: out of range: ") + bad);
     ctx->tune = *t;
     if (hipSetDevice(ctx->device) == hipSuccess) make_stream_plan(ctx);
@@ -2605,7 +2630,7 @@ struct StageTimer {
 
 
 template <bool COUNT>
-static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t stream, int block, bool lds, bool sort, uint32_t grid, size_t lds_bytes,
+static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t stream, int block, bool lds, bool sort, bool split, uint32_t grid, size_t lds_bytes,
                          const PassDev &ps, const SliceDev &sl, float *d_rgb_sum)
 {
     const int kind = ctx->kind;
@@ -2621,7 +2646,10 @@ static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t str
         if (sort) PT_LAUNCH_PATHS_K(L, B, true);                                 \
         else PT_LAUNCH_PATHS_K(L, B, false);                                     \
     } while (0)
-    if (lds) {
+    if (lds && split && !sort && kind == PT_KIND_SPHERES) { // (the one shape the two-ended queue is built for)
+        if (block == 256) hipLaunchKernelGGL((k_paths<COUNT, true, 256, false, PT_KIND_SPHERES, true>), dim3(grid), dim3(256), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+        else hipLaunchKernelGGL((k_paths<COUNT, true, 512, false, PT_KIND_SPHERES, true>), dim3(grid), dim3(512), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+    } else if (lds) {
         if (block == 256) PT_LAUNCH_PATHS_SC(true, 256);
         else PT_LAUNCH_PATHS_SC(true, 512);
     } else {
@@ -2899,14 +2927,18 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     SliceDev sl;
     sl.qA = ctx->d_sA; sl.qB = ctx->d_sB; sl.qC = ctx->d_sC; sl.rad = ctx->d_srad;
     sl.cap = cap; sl.pix_per_slice = pix; sl.n_slices = n_slices; sl.extents = ctx->d_extents; sl.ticket = ctx->d_ticket;
+    // Rays that head up are queued apart (k_paths, SPLIT) where they can leave the scene -- a background that is not black --
+    // on the kernel shape the form is built for (spheres in LDS); pt_tuning.split_queue overrides the first condition.
+    const bool open_scene = scene.bg[0] != 0.0f || scene.bg[1] != 0.0f || scene.bg[2] != 0.0f;
+    const bool split = tuned(ctx->tune.split_queue, open_scene ? 1 : 0) != 0;
     uint32_t n_passes = 0;
     for (uint32_t done = 0; done < pr->spp; done += spass, ++n_passes) {
         ps.samples = std::min(spass, pr->spp - done);
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (count) launch_paths<true>(ctx, scene, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
-        else launch_paths<false>(ctx, scene, stream, block, lds, sort, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (count) launch_paths<true>(ctx, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);
+        else launch_paths<false>(ctx, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }
     PT_HIP(ctx, hipGetLastError());

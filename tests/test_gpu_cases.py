@@ -83,6 +83,7 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth):
         assert s2["rays"] == st["rays"], tag
         assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tag
     for tune in (dict(block=256), dict(sort_by_material=1), dict(slice_paths=4096), dict(slice_paths=1000000),
+                 dict(split_queue=0), dict(split_queue=1),  # survivors in one queue / rays that head up queued apart
                  # scene in HBM: the streaming kernel (default there) at several batching thresholds and
                  # workgroup sizes, and the queue-based slice kernel
                  dict(hbm=1, stream_serve_min=1), dict(hbm=1, stream_serve_min=64),
