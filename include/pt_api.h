@@ -90,7 +90,7 @@ typedef struct pt_render_params {
 
 enum {
     PT_RENDER_STAGE_TIMES = 1u, /* time every kernel with events (slower; fills pt_stats.ms_*) */
-    PT_RENDER_NO_SORT = 2u,     /* never use the block-local material sort (it is opt-in: environment PT_PATHS_SORT=1) */
+    PT_RENDER_NO_SORT = 2u,     /* never use the block-local material sort (it is opt-in: pt_tuning.sort_by_material) */
     PT_RENDER_COUNT_TESTS = 4u, /* count box / object tests per ray (slower; fills pt_stats.box_tests / prim_tests) */
     PT_RENDER_NO_LDS_SCENE = 8u, /* traverse from global memory even when the scene would fit in LDS */
     PT_RENDER_SPLIT_KERNELS = 16u, /* one launch per stage and bounce over global queues instead of the persistent-workgroup kernel */

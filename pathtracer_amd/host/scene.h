@@ -71,19 +71,24 @@ public:
     {
         std::string line;
         try {
-            loadOptions(file, line);
-            loadCamera(file, line, aspect_ratio);
-            loadMaterials(file, line);
-            loadObjects(file, line);
-        } catch (const std::invalid_argument &e) {
-            throw pt_host::scene_error(std::string("scene file: malformed number near '") + line + "'");
-        } catch (const std::out_of_range &e) {
-            throw pt_host::scene_error(std::string("scene file: number out of range near '") + line + "'");
+            try {
+                loadOptions(file, line);
+                loadCamera(file, line, aspect_ratio);
+                loadMaterials(file, line);
+                loadObjects(file, line);
+            } catch (const std::invalid_argument &e) {
+                throw pt_host::scene_error(std::string("scene file: malformed number near '") + line + "'");
+            } catch (const std::out_of_range &e) {
+                throw pt_host::scene_error(std::string("scene file: number out of range near '") + line + "'");
+            }
+            if (hitables.empty()) throw pt_host::scene_error("scene file: the Objects section is empty");
+            for (material *m : materials) m->create_material_on_gpu();
+            finish_world();
+            cam->create_camera_on_gpu();
+        } catch (...) { // a constructor that throws runs no destructor: what the file gave so far is freed here
+            release();
+            throw;
         }
-        if (hitables.empty()) throw pt_host::scene_error("scene file: the Objects section is empty");
-        for (material *m : materials) m->create_material_on_gpu();
-        finish_world();
-        cam->create_camera_on_gpu();
     }
 
     void loadOptions(std::ifstream &file, std::string &line)
@@ -141,18 +146,23 @@ public:
         } while (line != "END");
     }
 
-    ~scene()
+    ~scene() { release(); }
+
+private:
+    void release()
     {
         for (hittable *h : hitables) delete h;
         for (material *m : materials) delete m;
+        hitables.clear();
+        materials.clear();
         if (world) {
             delete[] world->list;
             delete world;
+            world = nullptr;
         }
         delete cam;
+        cam = nullptr;
     }
-
-private:
     material *own(material *m)
     {
         materials.push_back(m);
@@ -162,11 +172,9 @@ private:
     void finish_world()
     {
         hittable **list = new hittable *[hitables.size()];
-        for (size_t i = 0; i < hitables.size(); ++i) {
-            list[i] = hitables[i];
-            list[i]->create_hittable_on_gpu();
-        }
-        world = new hittable_list(list, (int)hitables.size());
+        for (size_t i = 0; i < hitables.size(); ++i) list[i] = hitables[i];
+        world = new hittable_list(list, (int)hitables.size()); // owned from here on, whatever a create call below throws
+        for (size_t i = 0; i < hitables.size(); ++i) list[i]->create_hittable_on_gpu();
         world->create_hittable_on_gpu();
         world->copy_list_to_gpu();
     }
