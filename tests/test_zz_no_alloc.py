@@ -55,3 +55,30 @@ def test_noalloc_limits_and_arguments(ctx):
     with pytest.raises(api.PtError) as e:  # flags that need events or another pipeline
         ctx.render_device_noalloc(api.Context.params(8, 8, 1, 5, flags=api.RENDER_STAGE_TIMES), buf.data_ptr(), 0)
     assert e.value.status == 1
+
+
+def test_noalloc_is_capturable_into_a_graph(ctx):
+    """Stream capture refuses allocation, synchronisation and event queries: a capture that succeeds, runs nothing while
+    it records and reproduces pt_render_device's sums on every replay shows the entry point does none of them."""
+    ctx.upload(scenes.random_spheres_scene().desc())
+    w, h, spp, depth = 160, 90, 4, 20
+    p = api.Context.params(w, h, spp, depth)
+    ref = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    ctx.render_device(p, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        ctx.render_device_noalloc(p, got.data_ptr(), s.cuda_stream)
+        g.capture_end()
+    torch.cuda.synchronize()
+    assert float(got.abs().max()) == 0.0  # recorded, not run
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+    g.replay()  # the film accumulates: a second replay adds the same samples again, as a second pt_render_device call does
+    ctx.render_device(p, ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
