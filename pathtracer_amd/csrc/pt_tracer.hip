@@ -37,6 +37,7 @@ struct SceneDev {
     const float4 *mats;
     uint32_t n_prims, n_nodes;
     uint32_t stack_cap; // entries per lane in the LDS traversal stack
+    int32_t root_ref;   // where a render's traversal starts: 0, the root node; or the reference of the scene's only leaf
     const float4 *wide;      // the four-wide quantised form of the tree (pt::WideNode, 64 B each), for scenes traversed from HBM; or null
     uint32_t wide_stack_cap; // stack entries its traversal may use
     pt::ConeParams cone; // how wide a cone the slab test gives a ray
@@ -672,12 +673,15 @@ PT_DI void settle_parked(Nearest &nh, bool &need_exact)
 template <bool COUNT, int KIND, int STRIDE, class Src>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
-                            ProfLanes *prof = nullptr)
+                            ProfLanes *prof = nullptr, int32_t root = 0 /* wave-uniform: the root node, or the reference of the scene's only leaf */)
 {
     constexpr bool CONES = KIND == PT_KIND_ANY, SPH = KIND == PT_KIND_SPHERES;
     const float kappa = ray_kappa(src.cone, r.o);
-    BoxRay br = make_box_ray(r, kappa);
-    Src::adapt(br);
+    BoxRay br = {};
+    if (root >= 0) { // a scene that is one leaf has no box to test: no slab constants either
+        br = make_box_ray(r, kappa);
+        Src::adapt(br);
+    }
     // An axis whose far slot is open (rare).  Only followed up for scenes traversed from HBM, where such a ray
     // otherwise walks a large part of the tree; on the LDS-resident scenes (at most 1000 objects) the test costs
     // the kernel more registers than those rays cost it time (C2: 20.9 -> 22.1 ms with it).
@@ -696,7 +700,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     // depth + 2: a descent holds one entry per level.)
     stack[0] = (uint32_t)done;
     uint32_t sp = 1;
-    int32_t cur = 0; // root
+    int32_t cur = root;
     for (;;) {
         // Descend until this lane holds a leaf (or has nothing left); lanes that found theirs wait here, so
         // that the expensive object tests below run with as many lanes of the wave as possible.
@@ -834,6 +838,10 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     res.t = best_t;
     res.slot = best_slot;
     if (CONES && need_exact && !nan_hit) {
+        if (root < 0) { // (the replay walks the tree from its root)
+            br = make_box_ray(r, kappa);
+            Src::adapt(br);
+        }
         res = bvh_exact_scan<STRIDE>(src, stack_cap, r, br, t_min, t_max, stack, need_exact);
         n_replay++;
     }
@@ -1331,8 +1339,10 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     auto trace = [&](const Ray &r) -> HitResult {
         bool need_exact;
         HitResult h;
-        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
-        else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof);
+        // (the split-queue variant is the kernel of the large sphere fields: compiled without the one-leaf start, which costs it 0.5 %)
+        const int32_t root_ref = SPLIT ? 0 : sc.root_ref;
+        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
+        else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
         if (need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
@@ -2089,10 +2099,13 @@ static void *g_scratch[PT_MAX_DEVICES];
 // lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 1.  A leaf step
 // costs a wave the object code of every kind of object its lanes hold, once per position in the leaf that any lane
 // still has an object at; a node visit costs a fifth of that.  (1M spheres 3.04 / 3.20 / 3.27 Grays/s for 3 / 2 / 1,
-// 100k mixed objects 2.73 / 2.88 / 3.25 / 3.46 for 4 / 3 / 2 / 1.)  pt_tuning.leaf_max overrides.
+// 100k mixed objects 2.73 / 2.88 / 3.25 / 3.46 for 4 / 3 / 2 / 1.)  A scene of at most eight objects is one leaf: the
+// tree of the Cornell box (7 objects) costs more node visits than it saves object tests (leaves of 1 / 2 / 4 / 8:
+// 61.4 / 65.2 / 59.7 / 52.8 ms at 256 spp).  pt_tuning.leaf_max overrides.
 static uint32_t leaf_max_for(const pt_scene_desc *desc, const pt_tuning *tune = nullptr)
 {
     if (tune && tune->leaf_max > 0) return (uint32_t)tune->leaf_max;
+    if (desc->n_prims <= 8u) return 8u;
     return desc->n_prims > 1000u ? 1u : (uint32_t)PT_LEAF_MAX;
 }
 
@@ -2414,6 +2427,8 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.n_prims = desc->n_prims;
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 2); // one entry per level of a descent, and the "done" entry at the bottom
+    // a scene that is one leaf (at most eight objects): k_paths starts at the leaf, without the visit to a root whose one box every ray is in
+    sc.root_ref = b.nodes.size() == 1 && b.nodes[0].c[0] < 0 && !(b.nodes[0].b[0][1] < INFINITY) ? b.nodes[0].c[0] : 0;
     sc.cone = b.cone;
     const pt_camera &c = desc->camera;
     for (int k = 0; k < 3; ++k) {

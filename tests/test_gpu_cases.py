@@ -119,6 +119,48 @@ def test_tree_shape_does_not_change_the_image(ctx, name, w, h, spp, depth):
     assert np.array_equal(img.view(np.uint32), base.view(np.uint32))
 
 
+def _eight_objects_with_cones():
+    """Eight objects, wide cones first in the list and seen from above (rays steeper than their sides: the cone's larger root
+    first, cone.h:117), spheres and a cylinder that overlap them later in the list: the answers depend on list order."""
+    b = scenes.SceneBuilder(background=(0.7, 0.8, 1.0))
+    m = [b.lambertian((0.6, 0.5, 0.4)), b.metal((0.8, 0.8, 0.7), 0.1), b.dielectric(1.5), b.lambertian((0.2, 0.5, 0.7))]
+    b.cone((0.0, 0.0, 0.0), 1.0, 2.0, m[0])
+    b.cone((0.8, 0.2, 0.4), 1.5, 2.5, m[3])
+    b.cone((-1.0, 0.1, -0.6), 0.8, 1.5, m[1])
+    b.sphere((0.3, 0.6, 0.2), 0.7, m[2])
+    b.sphere((-0.8, 0.5, 0.9), 0.6, m[1])
+    b.cylinder2((1.2, 0.0, -0.8), 1.2, 0.5, m[0])
+    b.xz_rect(-4, 4, -4, 4, -0.1, m[3])
+    b.sphere((0.0, 1.4, 0.0), 0.3, m[0])
+    b.camera((0.6, 7.0, 0.9), (0.0, 0.3, 0.0), (0, 0, -1), 40.0, 1.0, 0.05, 7.0)
+    return b
+
+
+def test_scene_of_one_leaf(ctx):
+    """A scene of at most eight objects is one leaf, and k_paths starts at it without a root visit or slab constants.
+    Same image as with a real tree over the same objects (leaves of 2), from LDS and from HBM, as the oracle's, and the
+    exact replay of list-order dependent cone hits -- which walks the tree from its root -- still runs."""
+    b = _eight_objects_with_cones()
+    w, h, spp, depth = 96, 96, 4, 12
+    ctx.upload(b.desc())
+    nodes, order, _ = api.bvh_build_host(b.desc())
+    assert len(nodes) == 1 and nodes[0]["c"][0] < 0  # one leaf under the root
+    base, st = ctx.render(w, h, spp, depth)
+    assert st["exact_replays"] > 0
+    ref, rays = util.oracle_scene(b).render(w, h, spp, depth)
+    assert st["rays"] == rays
+    frac, rmse = _image_close(base, ref)
+    assert frac < 2e-3 and rmse < 2e-3, (frac, rmse)
+    for kw in (dict(flags=api.RENDER_NO_LDS_SCENE), dict(flags=api.RENDER_SPLIT_KERNELS)):
+        img, s2 = ctx.render(w, h, spp, depth, **kw)
+        assert s2["rays"] == rays and np.array_equal(img.view(np.uint32), base.view(np.uint32)), kw
+    with ctx.tuned(leaf_max=2):
+        ctx.upload(b.desc())
+    for flags in (0, api.RENDER_NO_LDS_SCENE):
+        img, s2 = ctx.render(w, h, spp, depth, flags=flags)
+        assert s2["rays"] == rays and np.array_equal(img.view(np.uint32), base.view(np.uint32)), flags
+
+
 def test_render_is_deterministic_and_seeded(ctx):
     ctx.upload(scenes.random_spheres_scene().desc())
     a, _ = ctx.render(160, 90, 3, 50)
