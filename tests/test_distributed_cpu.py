@@ -8,6 +8,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -67,3 +68,25 @@ def test_strong_sharding_two_ranks(tmp_path):
     full, full_rays = osc.render(W, H, SPP, DEPTH)
     assert rays == full_rays
     np.testing.assert_allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("spp", [8, 64, 100, 1024, 4096])
+def test_shards_tile_the_sample_range(world, spp):
+    """Strong: the ranks' ranges are contiguous, disjoint, cover [0, spp) and differ by at most one sample (config 3:
+    1024 spp over 1/2/4/8 GPUs, config 5: 4096 over 8).  Weak: rank r starts where rank r-1 ends and every rank has spp."""
+    at, sizes = 0, []
+    for r in range(world):
+        off, n = distributed.shard("strong", r, world, spp)
+        assert off == at and n >= 1
+        at += n
+        sizes.append(n)
+    assert at == spp and max(sizes) - min(sizes) <= 1
+    for r in range(world):
+        assert distributed.shard("weak", r, world, spp) == (r * spp, spp)
+    with pytest.raises(ValueError):
+        distributed.shard("strong", 0, spp + 1, spp)  # a rank without a sample
+    with pytest.raises(ValueError):
+        distributed.shard("strong", world, world, spp)
+    with pytest.raises(ValueError):
+        distributed.shard("neither", 0, world, spp)
