@@ -37,7 +37,7 @@ struct SceneDev {
     const float4 *mats;
     uint32_t n_prims, n_nodes;
     uint32_t stack_cap; // entries per lane in the LDS traversal stack
-    int32_t root_ref;   // where a render's traversal starts: 0, the root node; or the reference of the scene's only leaf
+    int32_t root_ref;   // the reference of the scene's only leaf where the tree is one (at most eight objects: the FLAT kernels start there), else 0
     const float4 *wide;      // the four-wide quantised form of the tree (pt::WideNode, 64 B each), for scenes traversed from HBM; or null
     uint32_t wide_stack_cap; // stack entries its traversal may use
     pt::ConeParams cone; // how wide a cone the slab test gives a ray
@@ -670,15 +670,15 @@ PT_DI void settle_parked(Nearest &nh, bool &need_exact)
 #define PT_KIND_SPHERES 0
 #define PT_KIND_NO_CONES 1
 #define PT_KIND_ANY 2
-template <bool COUNT, int KIND, int STRIDE, class Src>
+template <bool COUNT, int KIND, int STRIDE, class Src, bool FLAT = false /* the scene is one leaf, `root` its reference: no tree code at all */>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
-                            ProfLanes *prof = nullptr, int32_t root = 0 /* wave-uniform: the root node, or the reference of the scene's only leaf */)
+                            ProfLanes *prof = nullptr, int32_t root = 0 /* FLAT: the reference of the scene's only leaf */)
 {
     constexpr bool CONES = KIND == PT_KIND_ANY, SPH = KIND == PT_KIND_SPHERES;
     const float kappa = ray_kappa(src.cone, r.o);
     BoxRay br = {};
-    if (root >= 0) { // a scene that is one leaf has no box to test: no slab constants either
+    if (!FLAT) { // a scene that is one leaf has no box to test: no slab constants either
         br = make_box_ray(r, kappa);
         Src::adapt(br);
     }
@@ -698,13 +698,13 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     const int32_t done = INT32_MIN; // not a leaf reference: those are > INT32_MIN for fewer than 2^28 objects
     // The bottom entry of the stack says "done": a pop needs no test for an empty stack.  (The capacity is the tree's
     // depth + 2: a descent holds one entry per level.)
-    stack[0] = (uint32_t)done;
+    if (!FLAT) stack[0] = (uint32_t)done;
     uint32_t sp = 1;
-    int32_t cur = root;
+    int32_t cur = FLAT ? root : 0;
     for (;;) {
         // Descend until this lane holds a leaf (or has nothing left); lanes that found theirs wait here, so
         // that the expensive object tests below run with as many lanes of the wave as possible.
-        while (cur >= 0) {
+        while (!FLAT && cur >= 0) {
             float2 nx, ny, nz, fx, fy, fz;
             int32_t c0, c1;
             src.planes(cur, br, nx, ny, nz, fx, fy, fz, c0, c1);
@@ -815,6 +815,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
         // A hit at t = NaN was accepted (the reference's comparisons let it through, and from then on what the scan
         // accepts is a matter of list order: every later entry the ray's line crosses): the list itself answers this ray.
         if (!SPH && best_t != best_t) { nan_hit = true; break; }
+        if (FLAT) break; // the one leaf is done
         cur = (int32_t)stack[(--sp) * STRIDE];
         if (cur == done) break;
     }
@@ -838,7 +839,7 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     res.t = best_t;
     res.slot = best_slot;
     if (CONES && need_exact && !nan_hit) {
-        if (root < 0) { // (the replay walks the tree from its root)
+        if (FLAT) { // (the replay walks the tree from its root)
             br = make_box_ray(r, kappa);
             Src::adapt(br);
         }
@@ -1298,7 +1299,7 @@ struct SliceDev {
     uint32_t *ticket;
 };
 
-template <bool COUNT, bool LDS, int BLOCK, bool SORT, int KIND, bool SPLIT = false>
+template <bool COUNT, bool LDS, int BLOCK, bool SORT, int KIND, bool SPLIT = false, bool FLAT = false>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, SliceDev sl, float *__restrict__ rgb_sum, Counters *cnt)
 {
     constexpr int WAVES = BLOCK / 64;
@@ -1339,10 +1340,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
     auto trace = [&](const Ray &r) -> HitResult {
         bool need_exact;
         HitResult h;
-        // (the split-queue variant is the kernel of the large sphere fields: compiled without the one-leaf start, which costs it 0.5 %)
-        const int32_t root_ref = SPLIT ? 0 : sc.root_ref;
-        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
-        else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
+        const int32_t root_ref = FLAT ? sc.root_ref : 0; // (a run-time start reference in the kernels with tree code costs them 0.5 %)
+        if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK, LdsSrc, FLAT>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
+        else h = bvh_nearest<COUNT, KIND, BLOCK, GlobalSrc, FLAT>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
         if (need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
@@ -2427,7 +2427,7 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.n_prims = desc->n_prims;
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 2); // one entry per level of a descent, and the "done" entry at the bottom
-    // a scene that is one leaf (at most eight objects): k_paths starts at the leaf, without the visit to a root whose one box every ray is in
+    // a scene that is one leaf (at most eight objects): k_paths' FLAT kernels start at the leaf, without the visit to a root whose one box every ray is in
     sc.root_ref = b.nodes.size() == 1 && b.nodes[0].c[0] < 0 && !(b.nodes[0].b[0][1] < INFINITY) ? b.nodes[0].c[0] : 0;
     sc.cone = b.cone;
     const pt_camera &c = desc->camera;
@@ -2661,7 +2661,15 @@ static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t str
         if (sort) PT_LAUNCH_PATHS_K(L, B, true);                                 \
         else PT_LAUNCH_PATHS_K(L, B, false);                                     \
     } while (0)
-    if (lds && split && !sort && kind == PT_KIND_SPHERES) { // (the one shape the two-ended queue is built for)
+    if (!COUNT && lds && !sort && scene.root_ref < 0 && kind != PT_KIND_SPHERES) { // a scene of one leaf: the kernels without tree code
+        if (kind == PT_KIND_ANY) {
+            if (block == 256) hipLaunchKernelGGL((k_paths<false, true, 256, false, PT_KIND_ANY, false, true>), dim3(grid), dim3(256), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+            else hipLaunchKernelGGL((k_paths<false, true, 512, false, PT_KIND_ANY, false, true>), dim3(grid), dim3(512), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+        } else {
+            if (block == 256) hipLaunchKernelGGL((k_paths<false, true, 256, false, PT_KIND_NO_CONES, false, true>), dim3(grid), dim3(256), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+            else hipLaunchKernelGGL((k_paths<false, true, 512, false, PT_KIND_NO_CONES, false, true>), dim3(grid), dim3(512), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
+        }
+    } else if (lds && split && !sort && kind == PT_KIND_SPHERES) { // (the one shape the two-ended queue is built for)
         if (block == 256) hipLaunchKernelGGL((k_paths<COUNT, true, 256, false, PT_KIND_SPHERES, true>), dim3(grid), dim3(256), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
         else hipLaunchKernelGGL((k_paths<COUNT, true, 512, false, PT_KIND_SPHERES, true>), dim3(grid), dim3(512), lds_bytes, stream, scene, ps, sl, d_rgb_sum, ctx->d_cnt);
     } else if (lds) {
