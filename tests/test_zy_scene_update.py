@@ -98,3 +98,28 @@ def test_update_of_a_large_scene_and_errors(ctx):
         fresh.update(after.desc())
     assert e.value.status == 2  # PT_ERR_NO_SCENE
     fresh.close()
+
+
+@pytest.mark.gpu
+def test_update_of_a_one_leaf_scene(ctx):
+    """The Cornell box (seven objects: one leaf, rendered by the kernels without tree code) with its cylinder and
+    its light moved: the updated scene renders what a fresh upload of it renders."""
+    before = scenes.cornell_scene()
+    a = {k: np.array(v, copy=True) for k, v in before.arrays().items()}
+    cyl = a["prim_type"] == api.CYLINDER
+    assert cyl.sum() == 1 and len(a["prim_type"]) <= 8
+    a["prim_param"][cyl, 0] -= np.float32(120.0)
+    a["prim_param"][cyl, 2] += np.float32(90.0)
+    a["prim_param"][-1, 4] -= np.float32(30.0)  # the light, an xz_rect, comes down
+    after = scenes.ArrayScene(a, before.background, before.camera_args)
+    ctx.upload(before.desc())
+    img_before, _ = ctx.render(64, 64, 4, 8)
+    ctx.update(after.desc())
+    img_refit, st_refit = ctx.render(64, 64, 4, 8)
+    ctx.upload(after.desc())
+    img_fresh, st_fresh = ctx.render(64, 64, 4, 8)
+    assert st_refit["rays"] == st_fresh["rays"]
+    assert np.array_equal(img_refit.view(np.uint32), img_fresh.view(np.uint32))
+    assert not np.array_equal(img_refit.view(np.uint32), img_before.view(np.uint32))
+    ref, rays = util.oracle_scene(after).render(64, 64, 4, 8)
+    assert st_fresh["rays"] == rays
