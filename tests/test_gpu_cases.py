@@ -576,3 +576,25 @@ def test_group_of_one_gpu_goes_through_rccl(ctx):
         assert np.array_equal(small.view(np.uint32), ref.view(np.uint32))
     with pytest.raises(api.PtError):
         api.Group([0, 0])  # one rank per GPU
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tiny_random_scenes(ctx, seed):
+    """Scenes of 1 to 12 objects of every kind (up to eight objects: one leaf, rendered by the kernels without tree
+    code; above: the smallest trees): the oracle's paths ray for ray, traces bit-exact."""
+    n = 1 + (seed * 5) % 12
+    b = scenes.mixed_scene(n=n, seed=100 + seed, extent=4.0, n_materials=6)
+    osc = util.oracle_scene(b)
+    ctx.upload(b.desc())
+    o, d = util.mixed_rays(b, osc, 4000, seed=seed)
+    ref = osc.trace(o, d)
+    got = ctx.trace(o, d, mode=api.TRACE_BVH_IN_SCENE)
+    assert not (util.hits_equal(got, ref) & (ref["nan_flag"] == 0)).any(), (seed, n)
+    w, h, spp, depth = 48, 32, 3, 10
+    img, st = ctx.render(w, h, spp, depth)
+    want, rays = osc.render(w, h, spp, depth)
+    assert st["rays"] == rays, (seed, n, st["rays"], rays)
+    frac, rmse = _image_close(img, want)
+    assert frac < 2e-3 and rmse < 2e-3, (seed, n, frac, rmse)
+    alt, s2 = ctx.render(w, h, spp, depth, flags=api.RENDER_NO_LDS_SCENE)
+    assert s2["rays"] == rays and np.array_equal(alt.view(np.uint32), img.view(np.uint32)), (seed, n)
