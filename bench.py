@@ -3,9 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload c2]
 
-A step is one full render of the workload's image on every rank: each rank renders its own range of
-absolute sample indices (--scaling weak, the default: `spp` samples per GPU, the image gets N*spp;
---scaling strong: the workload's spp cut into N ranges), the linear accumulation buffers are summed
+A step is one full render of the workload's image: each rank renders its own range of absolute
+sample indices (--scaling strong, the default: the workload's spp cut into N contiguous ranges, so
+the image is the named configuration's whatever N is; --scaling weak: `spp` samples per GPU, the
+image gets N*spp), the linear accumulation buffers are summed
 with one RCCL all-reduce (on its own stream, overlapped with the next step's render), and every rank
 holds the result.  Inputs (scene, BVH) are resident in HBM before the timed region.  Prints ONE JSON
 line on rank 0.
@@ -96,8 +97,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1984)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", default=os.environ.get("PT_BENCH_SCALING", "weak"), choices=["weak", "strong"],
-                    help="weak: every GPU renders the workload's spp (the image gets N x spp); strong: the workload's spp is cut into N ranges")
+    ap.add_argument("--scaling", default=os.environ.get("PT_BENCH_SCALING", "strong"), choices=["weak", "strong"],
+                    help="strong (default): the workload's spp is cut into N ranges, the image is the named configuration's; weak: every GPU renders the workload's spp (the image gets N x spp)")
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
     ap.add_argument("--force-collective", action="store_true", help="with one GPU: still create the process group (one rank) and run the all-reduce on its stream, to rehearse the N > 1 code path")
     ap.add_argument("--cull", default="cone", choices=["cone", "geometric"], help="geometric: PT_RENDER_GEOMETRIC_CULL (labelled in the output; not the headline configuration)")

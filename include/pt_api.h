@@ -205,6 +205,13 @@ pt_status pt_render(pt_context *ctx, const pt_render_params *params, float *rgb_
 pt_status pt_render_device(pt_context *ctx, const pt_render_params *params, float *d_rgb_sum, void *stream,
                            pt_stats *stats);
 
+/* Page-locked host memory for the buffers pt_render and pt_group_render fill (the reference's fb is managed memory read
+ * back by page migration, main.cu:167-170, :192-205): a film in such a buffer arrives at the link's rate, a pageable one
+ * (malloc, numpy) at about a fifth of it through the library's own staging buffer.  Either kind is accepted.  NULL on
+ * failure; free with pt_host_free. */
+void *pt_host_alloc(size_t bytes);
+void pt_host_free(void *p);
+
 /* pt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  It has no counterpart in the reference.  It calls no hipMalloc / hipFree / event or stream creation
  * and synchronises nothing: the scene must have been uploaded (and pt_context_configure called, if at all) beforehand,
@@ -221,7 +228,7 @@ pt_status pt_render_device_noalloc(pt_context *ctx, const pt_render_params *para
  * A group holds one context per GPU and one RCCL communicator over them (RCCL is loaded on first use); the scene is
  * replicated; pt_group_render cuts params->spp into one contiguous range of absolute sample indices per GPU
  * ([g spp / G, (g + 1) spp / G) from params->sample_offset), renders them concurrently (pt_render_device, one host
- * thread per GPU), sums the linear accumulation buffers with one ncclAllReduce over xGMI and copies the sum to the
+ * thread per GPU that lives as long as the group), sums the linear accumulation buffers with one ncclAllReduce over xGMI and copies the sum to the
  * host: feed it to pt_film_finalize with the total spp (the gamma is non-linear and must come after the reduction).
  * The image is that of a single pt_render of the same parameters except for the fp32 association of the per-pixel sum.
  * stats: counters summed over the GPUs, ms_total the whole call on the host's clock. */
@@ -233,6 +240,14 @@ const char *pt_group_last_error(const pt_group *g);
 pt_status pt_group_configure(pt_group *g, const pt_tuning *t);
 pt_status pt_group_scene_upload(pt_group *g, const pt_scene_desc *desc);
 pt_status pt_group_render(pt_group *g, const pt_render_params *params, float *rgb_sum_host, pt_stats *stats);
+/* The same without the copy to the host, for callers that finish on the device: *d_rgb_sum is GPU 0's buffer of the
+ * whole image's linear sums (every GPU of the group holds the same sums), owned by the group and valid until the next
+ * call on it; all of the group's streams are idle on return. */
+pt_status pt_group_render_device(pt_group *g, const pt_render_params *params, const float **d_rgb_sum, pt_stats *stats);
+/* The range of absolute sample indices GPU `rank` of `n_ranks` renders in pt_group_render: [sample_offset, sample_offset +
+ * spp) cut into contiguous ranges that differ by at most one sample.  Host arithmetic only (no GPU needed);
+ * PT_ERR_INVALID if spp < n_ranks (every GPU needs a sample). */
+pt_status pt_group_shard(uint32_t spp, uint32_t sample_offset, int n_ranks, int rank, uint32_t *offset, uint32_t *count);
 
 /* main.cu:95-98 and :192-205: mean over total_spp (multiply by the reciprocal, vec3.h:136-138), sqrt
  * gamma, then int(256*clamp(c,0,0.999)) with rows written top-down from j = H-1.  Host buffers;

@@ -656,13 +656,17 @@ uint64_t orc_render_region(const orc_scene *s, int width, int height, int x0, in
 {
     uint64_t total = 0;
     if (threads <= 0) threads = orc_num_threads();
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total) num_threads(threads)
-    for (int jj = 0; jj < h; ++jj) {
+    /* pixels are independent: dealt out in runs short enough that a crop of a few pixels still uses every thread */
+    const long n_px = (long)w * h;
+    long run = n_px / ((long)threads * 16);
+    if (run < 1) run = 1;
+    if (run > w) run = w;
+#pragma omp parallel for schedule(dynamic, run) reduction(+ : total) num_threads(threads)
+    for (long px = 0; px < n_px; ++px) {
+        const int jj = (int)(px / w), ii = (int)(px - (long)jj * w);
         uint64_t rays = 0;
-        for (int ii = 0; ii < w; ++ii) {
-            v3 c = pixel_sum(s, x0 + ii, y0 + jj, width, height, sample0, n_samples, depth, seed, &rays);
-            vstore(rgb_sum + ((size_t)jj * w + ii) * 3, c);
-        }
+        v3 c = pixel_sum(s, x0 + ii, y0 + jj, width, height, sample0, n_samples, depth, seed, &rays);
+        vstore(rgb_sum + (size_t)px * 3, c);
         total += rays;
     }
     return total;

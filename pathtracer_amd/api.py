@@ -29,6 +29,7 @@ EXPORTS = [
     "pt_bvh_build_host", "pt_bvh_build_host_leaf", "pt_bvh_refit_host", "pt_bvh_wide_host", "pt_scene_ray_cone", "pt_version",
     "pt_tuning_default", "pt_context_configure", "pt_render_device_noalloc", "pt_scatter_batch",
     "pt_group_create", "pt_group_destroy", "pt_group_size", "pt_group_last_error", "pt_group_configure", "pt_group_scene_upload", "pt_group_render",
+    "pt_group_render_device", "pt_group_shard", "pt_host_alloc", "pt_host_free",
 ]
 
 
@@ -156,6 +157,12 @@ def lib():
         L.pt_group_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
         L.pt_group_scene_upload.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
         L.pt_group_render.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.POINTER(PtStats)]
+        L.pt_group_render_device.argtypes = [C.c_void_p, C.POINTER(PtRenderParams), C.POINTER(C.c_void_p), C.POINTER(PtStats)]
+        L.pt_group_shard.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pt_host_alloc.argtypes = [C.c_size_t]
+        L.pt_host_alloc.restype = C.c_void_p
+        L.pt_host_free.argtypes = [C.c_void_p]
+        L.pt_host_free.restype = None
         L.pt_tuning_default.argtypes = [C.POINTER(PtTuning)]
         L.pt_tuning_default.restype = None
         L.pt_context_configure.argtypes = [C.c_void_p, C.POINTER(PtTuning)]
@@ -277,6 +284,39 @@ def scene_ray_cone(desc):
             "adaptive": bool(out.adaptive)}
 
 
+def group_shard(spp, sample_offset, n_ranks, rank):
+    """pt_group_shard: (first absolute sample, samples) of GPU `rank` of `n_ranks` in pt_group_render (host arithmetic)."""
+    off, cnt = C.c_uint32(0), C.c_uint32(0)
+    st = lib().pt_group_shard(spp, sample_offset, n_ranks, rank, C.byref(off), C.byref(cnt))
+    if st != PT_OK:
+        raise PtError(st, "pt_group_shard(spp=%d, n_ranks=%d, rank=%d)" % (spp, n_ranks, rank))
+    return off.value, cnt.value
+
+
+class PinnedFilm:
+    """A (height, width, 3) float32 array in page-locked host memory (pt_host_alloc): pt_render and pt_group_render
+    fill it at the link's rate.  Keep the object alive while the array is in use; close() frees the memory."""
+
+    def __init__(self, height, width):
+        n = height * width * 3
+        self._p = lib().pt_host_alloc(n * 4)
+        if not self._p:
+            raise MemoryError("pt_host_alloc(%d bytes) failed" % (n * 4))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_float)), shape=(n,)).reshape(height, width, 3)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().pt_host_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def film_finalize(rgb_sum, total_spp):
     """main.cu:95-98 and :192-205: returns (gamma image bottom-up float32, 8-bit image top-down)."""
     rgb_sum = np.ascontiguousarray(rgb_sum, dtype=np.float32)
@@ -386,10 +426,14 @@ class Context:
         p.max_depth, p.seed, p.samples_per_pass, p.flags = max_depth, seed, samples_per_pass, flags
         return p
 
-    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, samples_per_pass=0, flags=0):
-        """Returns (rgb_sum[h, w, 3] float32 linear sums, stats dict)."""
+    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, samples_per_pass=0, flags=0, out=None):
+        """Returns (rgb_sum[h, w, 3] float32 linear sums, stats dict).  `out`: a C-contiguous float32 (h, w, 3) array to
+        fill instead of a new one (a PinnedFilm's array arrives at the link's rate)."""
         p = self.params(width, height, spp, max_depth, seed, sample_offset, samples_per_pass, flags)
-        out = np.zeros((height, width, 3), dtype=np.float32)
+        if out is None:
+            out = np.zeros((height, width, 3), dtype=np.float32)
+        elif out.shape != (height, width, 3) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape (height, width, 3)")
         stats = PtStats()
         self._check(lib().pt_render(self._h, C.byref(p), out.ctypes.data, C.byref(stats)))
         return out, stats.as_dict()
@@ -437,10 +481,22 @@ class Group:
     def upload(self, desc):
         self._check(lib().pt_group_scene_upload(self._h, C.byref(desc.c)))
 
-    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, flags=0):
+    def render(self, width, height, spp, max_depth, seed=1984, sample_offset=0, flags=0, out=None):
         """Returns (rgb_sum[h, w, 3] float32 linear sums over all GPUs' samples, stats dict)."""
         p = Context.params(width, height, spp, max_depth, seed, sample_offset, 0, flags)
-        out = np.zeros((height, width, 3), dtype=np.float32)
+        if out is None:
+            out = np.zeros((height, width, 3), dtype=np.float32)
+        elif out.shape != (height, width, 3) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape (height, width, 3)")
         stats = PtStats()
         self._check(lib().pt_group_render(self._h, C.byref(p), out.ctypes.data, C.byref(stats)))
         return out, stats.as_dict()
+
+    def render_device(self, width, height, spp, max_depth, seed=1984, sample_offset=0, flags=0):
+        """pt_group_render_device: returns (device address of GPU 0's buffer of the summed image, stats dict); the buffer
+        belongs to the group and is valid until the next call on it."""
+        p = Context.params(width, height, spp, max_depth, seed, sample_offset, 0, flags)
+        ptr = C.c_void_p()
+        stats = PtStats()
+        self._check(lib().pt_group_render_device(self._h, C.byref(p), C.byref(ptr), C.byref(stats)))
+        return ptr.value, stats.as_dict()

@@ -2084,16 +2084,18 @@ struct pt_context {
     hipEvent_t last_done = nullptr; // end of the last call that enqueued work using the workspace above
     bool have_last = false;
     struct StreamPlan *stream_plan = nullptr; // launch shape of the streaming pipeline for the installed scene (pt_render_device_noalloc)
+    void *scratch = nullptr;     // this GPU's address of the no-allocation scratch array (hipGetSymbolAddress, pt_context_create)
+    // pt_render: the device film and a pinned staging buffer, kept across calls
+    float *d_film = nullptr, *h_film = nullptr;
+    size_t cap_film = 0, cap_hfilm = 0;
 };
 
 static int tuned(int32_t v, int dflt) { return v >= 0 ? (int)v : dflt; }
 
 // The scratch of pt_render_device_noalloc: one array per GPU inside the code object.  Host code never uses the
-// array's name as an address; g_scratch[device] holds what hipGetSymbolAddress returned with that device current.
+// array's name as an address; a context holds what hipGetSymbolAddress returned with its device current.
 #define PT_SCRATCH_HEADER 1024u // the pass counter at byte 0, the Counters record at byte 256
 static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_HEADER + PT_NOALLOC_SCRATCH_BYTES];
-#define PT_MAX_DEVICES 64
-static void *g_scratch[PT_MAX_DEVICES];
 
 // Objects per BVH leaf.  Scenes small enough to be traversed from LDS do best with 4 (3 and 4 tie, 2 and 6
 // lose 10-20 %).  Scenes traversed from HBM by k_paths_stream, which is bound by instruction issue: 1.  A leaf step
@@ -2140,13 +2142,9 @@ extern "C" pt_status pt_context_create(int device_id, pt_context **out)
     if (hipEventCreateWithFlags(&ctx->last_done, hipEventDisableTiming) != hipSuccess) { hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx; return PT_ERR_DEVICE; }
     pt_tuning_default(&ctx->tune);
     // this GPU's copy of the no-allocation scratch array (each GPU holds its own, at its own address)
-    if (device_id < PT_MAX_DEVICES && !g_scratch[device_id]) {
-        void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
-            hipEventDestroy(ctx->last_done); hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx;
-            return PT_ERR_DEVICE;
-        }
-        g_scratch[device_id] = p;
+    if (hipGetSymbolAddress(&ctx->scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->scratch) {
+        hipEventDestroy(ctx->last_done); hipFree(ctx->d_cnt); hipStreamDestroy(ctx->own_stream); delete ctx;
+        return PT_ERR_DEVICE;
     }
     *out = ctx;
     return PT_OK;
@@ -2216,6 +2214,8 @@ extern "C" void pt_context_destroy(pt_context *ctx)
     hipFree(ctx->d_nactive); hipFree(ctx->d_cnt);
     hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad); hipFree(ctx->d_ticket);
     hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
+    hipFree(ctx->d_film);
+    if (ctx->h_film) hipHostFree(ctx->h_film);
     for (hipEvent_t e : ctx->events) hipEventDestroy(e);
     if (ctx->last_done) hipEventDestroy(ctx->last_done);
     drop_stream_plan(ctx);
@@ -2917,6 +2917,9 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
             ext.push_back(make_uint2(at, take));
             at += take;
         }
+        // A previous call on another stream may still read the table (the event wait that orders calls behind each other
+        // orders device work only, and the copy below is host-timed): wait for it to finish first.
+        if (ctx->have_last) PT_HIP(ctx, hipEventSynchronize(ctx->last_done));
         if (ext.size() > ctx->cap_extents) {
             hipFree(ctx->d_extents);
             ctx->d_extents = nullptr; ctx->cap_extents = 0;
@@ -3018,8 +3021,13 @@ static pt_status stream_passes(pt_context *ctx, const pt_render_params *pr, floa
     const uint32_t tile = (uint32_t)tuned(tu.stream_tile, 64);
     uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::min(pr->spp, 256u);
     spass = std::min(spass, pr->spp);
-    if ((uint64_t)spass * tile > rad_cap_paths) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for the pass buffer");
-    const uint32_t band_pix = (uint32_t)std::min<uint64_t>(n_pixels, rad_cap_paths / spass / tile * tile);
+    // A frame whose pass fits the buffer is one band whatever its pixel count; only a frame that has to be cut is cut
+    // at tile boundaries (a band's last tile may be short, a band's first may not).
+    uint32_t band_pix = n_pixels;
+    if ((uint64_t)spass * n_pixels > rad_cap_paths) {
+        if ((uint64_t)spass * tile > rad_cap_paths) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for the pass buffer");
+        band_pix = (uint32_t)(rad_cap_paths / spass / tile * tile);
+    }
     if ((uint64_t)spass * band_pix >= (1ull << 32) - (1ull << 24)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one pass"); // the path counter overshoots by up to 64 per wave
     PassDev ps;
     ps.width = (uint32_t)pr->width; ps.height = (uint32_t)pr->height; ps.n_pixels = n_pixels;
@@ -3086,11 +3094,11 @@ extern "C" pt_status pt_render_device_noalloc(pt_context *ctx, const pt_render_p
     if (chk != PT_OK) return chk;
     if ((pr->flags & ~(uint32_t)PT_RENDER_GEOMETRIC_CULL) != 0) return fail(ctx, PT_ERR_INVALID, "pt_render_device_noalloc takes no flag but PT_RENDER_GEOMETRIC_CULL");
     if ((uint64_t)pr->width * (uint64_t)pr->height * pr->spp > (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "pt_render_device_noalloc: more than 2^32 paths (width * height * spp) in one call");
-    if (ctx->device >= PT_MAX_DEVICES || !g_scratch[ctx->device]) return fail(ctx, PT_ERR_DEVICE, "no scratch array on this device");
+    if (!ctx->scratch) return fail(ctx, PT_ERR_DEVICE, "no scratch array on this device");
     if (!ctx->stream_plan) return fail(ctx, PT_ERR_NO_SCENE, "no launch plan: upload the scene first");
     hipStream_t stream = (hipStream_t)stream_;
     PT_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned char *base = static_cast<unsigned char *>(g_scratch[ctx->device]); // never the array's name: that is a host-side stand-in
+    unsigned char *base = static_cast<unsigned char *>(ctx->scratch); // never the array's name: that is a host-side stand-in
     uint32_t *ticket = reinterpret_cast<uint32_t *>(base);
     Counters *cnt = reinterpret_cast<Counters *>(base + 256);
     float *rad = reinterpret_cast<float *>(base + PT_SCRATCH_HEADER);
@@ -3231,6 +3239,73 @@ static pt_status render_device_impl(pt_context *ctx, const pt_render_params *pr,
     return PT_OK;
 }
 
+// Pinned host memory for the callers' film buffers: a device-to-host copy into it runs at the link's rate (about
+// 50 GB/s) instead of the 9 GB/s of a copy into pageable memory, which the runtime stages through its own buffers.
+extern "C" void *pt_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void pt_host_free(void *p)
+{
+    if (p) hipHostFree(p);
+}
+
+// true if [p, p + bytes) is pinned host memory the device can copy into directly
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // an ordinary malloc'ed pointer is reported as an error: not one
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// Device buffer -> caller's host buffer on `stream`, synchronised.  A pinned destination (pt_host_alloc) is written
+// directly.  A pageable one goes through the context's pinned staging buffer in chunks, the copy of chunk k + 1 from
+// the device overlapping the host's copy of chunk k out of the staging buffer.
+static hipError_t copy_film_to_host(pt_context *ctx, float *dst, const float *d_src, size_t bytes, hipStream_t stream)
+{
+    hipError_t e;
+    if (is_pinned_host(dst)) {
+        if ((e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        return hipStreamSynchronize(stream);
+    }
+    const size_t chunk = 4u << 20;
+    if (ctx->cap_hfilm < 2 * chunk) {
+        if (ctx->h_film) hipHostFree(ctx->h_film);
+        ctx->h_film = nullptr; ctx->cap_hfilm = 0;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_film), 2 * chunk, hipHostMallocDefault)) != hipSuccess) return e;
+        ctx->cap_hfilm = 2 * chunk;
+    }
+    if (ctx->events.size() < 2) {
+        while (ctx->events.size() < 2) {
+            hipEvent_t ev;
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return e;
+            ctx->events.push_back(ev);
+        }
+    }
+    char *stage[2] = {reinterpret_cast<char *>(ctx->h_film), reinterpret_cast<char *>(ctx->h_film) + chunk};
+    const char *src = reinterpret_cast<const char *>(d_src);
+    char *out = reinterpret_cast<char *>(dst);
+    const size_t n = (bytes + chunk - 1) / chunk;
+    auto len = [&](size_t k) { return std::min(chunk, bytes - k * chunk); };
+    if ((e = hipMemcpyAsync(stage[0], src, len(0), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ctx->events[0], stream)) != hipSuccess) return e;
+    for (size_t k = 0; k < n; ++k) {
+        if (k + 1 < n) {
+            if ((e = hipMemcpyAsync(stage[(k + 1) & 1], src + (k + 1) * chunk, len(k + 1), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ctx->events[(k + 1) & 1], stream)) != hipSuccess) return e;
+        }
+        if ((e = hipEventSynchronize(ctx->events[k & 1])) != hipSuccess) return e;
+        memcpy(out + k * chunk, stage[k & 1], len(k));
+    }
+    return hipSuccess;
+}
+
 extern "C" pt_status pt_render(pt_context *ctx, const pt_render_params *pr, float *rgb_sum_host, pt_stats *stats)
 {
     if (!ctx) return PT_ERR_INVALID;
@@ -3238,17 +3313,19 @@ extern "C" pt_status pt_render(pt_context *ctx, const pt_render_params *pr, floa
     if (pr->width <= 0 || pr->height <= 0) return fail(ctx, PT_ERR_INVALID, "width and height must be positive");
     PT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)pr->width * pr->height * 3 * sizeof(float);
-    float *d_sum = nullptr;
-    PT_HIP(ctx, hipMalloc(&d_sum, bytes));
-    hipError_t e = hipMemsetAsync(d_sum, 0, bytes, ctx->own_stream);
-    pt_status st = e == hipSuccess ? pt_render_device(ctx, pr, d_sum, ctx->own_stream, stats) : fail(ctx, PT_ERR_DEVICE, hipGetErrorString(e));
-    if (st == PT_OK) {
-        e = hipMemcpyAsync(rgb_sum_host, d_sum, bytes, hipMemcpyDeviceToHost, ctx->own_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->own_stream);
-        if (e != hipSuccess) st = fail(ctx, PT_ERR_DEVICE, hipGetErrorString(e));
+    if (bytes > ctx->cap_film) { // the device film is kept across calls (the reference's fb lives as long as main, main.cu:167-170)
+        PT_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
+        hipFree(ctx->d_film);
+        ctx->d_film = nullptr; ctx->cap_film = 0;
+        PT_HIP(ctx, hipMalloc(&ctx->d_film, bytes));
+        ctx->cap_film = bytes;
     }
-    hipFree(d_sum);
-    return st;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_film, 0, bytes, ctx->own_stream));
+    const pt_status st = pt_render_device(ctx, pr, ctx->d_film, ctx->own_stream, stats);
+    if (st != PT_OK) return st;
+    const hipError_t e = copy_film_to_host(ctx, rgb_sum_host, ctx->d_film, bytes, ctx->own_stream);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_DEVICE, std::string("pt_render: ") + hipGetErrorString(e));
+    return PT_OK;
 }
 
 // main.cu:95-98 and :192-205 (host).

@@ -126,9 +126,11 @@ public:
         return it->second;
     }
 
-    // Linear sums of `spp` samples per pixel (pt_render); uploads the world/camera pair if it changed.
-    void render_sum(const void *world_handle, const void *camera_handle, const float background[3], int width, int height, int spp,
-                    std::vector<float> &sum, pt_stats *stats = nullptr)
+    // Linear sums of `spp` samples per pixel (pt_render); uploads the world/camera pair if it changed.  The sums arrive in
+    // a page-locked buffer the session keeps (the device writes it at the link's rate; the reference reads its managed fb
+    // back by page migration, main.cu:167-170, :192-205): valid until the next call.
+    const float *render_sum(const void *world_handle, const void *camera_handle, const float background[3], int width, int height, int spp,
+                            pt_stats *stats = nullptr)
     {
         ensure_context();
         if (uploaded_world_ != world_handle || uploaded_camera_ != camera_handle || std::memcmp(uploaded_bg_, background, 12) != 0) {
@@ -155,9 +157,17 @@ public:
         p.spp = (uint32_t)spp;
         p.max_depth = options.max_depth;
         p.seed = options.seed;
-        sum.assign((size_t)width * height * 3, 0.0f);
-        if (grp_) check_group(pt_group_render(grp_, &p, sum.data(), stats), "pt_group_render");
-        else check(pt_render(ctx_, &p, sum.data(), stats), "pt_render");
+        const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+        if (bytes > film_bytes_) {
+            pt_host_free(film_);
+            film_bytes_ = 0;
+            film_ = static_cast<float *>(pt_host_alloc(bytes));
+            if (!film_) throw scene_error("pt_host_alloc: no page-locked memory for the film");
+            film_bytes_ = bytes;
+        }
+        if (grp_) check_group(pt_group_render(grp_, &p, film_, stats), "pt_group_render");
+        else check(pt_render(ctx_, &p, film_, stats), "pt_render");
+        return film_;
     }
 
     // Forgets every snapshot (the scene on the GPU stays until the next upload).
@@ -170,6 +180,7 @@ public:
 
     ~Session()
     {
+        pt_host_free(film_);
         if (ctx_) pt_context_destroy(ctx_);
         if (grp_) pt_group_destroy(grp_);
     }
@@ -203,6 +214,8 @@ private:
     std::map<const void *, pt_camera> cameras_;
     pt_context *ctx_ = nullptr;
     pt_group *grp_ = nullptr;
+    float *film_ = nullptr; // page-locked (pt_host_alloc)
+    size_t film_bytes_ = 0;
     const void *uploaded_world_ = nullptr, *uploaded_camera_ = nullptr;
     float uploaded_bg_[3] = {0, 0, 0};
 };

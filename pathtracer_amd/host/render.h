@@ -18,10 +18,10 @@ inline void render(vec3 *fb, int max_x, int max_y, int samples_per_pixel, color 
                    pt_stats *stats = nullptr)
 {
     if (!fb || !cam || !world) throw scene_error("render(): null frame buffer, camera or world handle");
-    std::vector<float> sum, gamma((size_t)max_x * max_y * 3);
+    std::vector<float> gamma((size_t)max_x * max_y * 3);
     const float bg[3] = {background.x(), background.y(), background.z()};
-    Session::get().render_sum(world, cam, bg, max_x, max_y, samples_per_pixel, sum, stats);
-    if (pt_film_finalize(sum.data(), max_x, max_y, (uint32_t)samples_per_pixel, gamma.data(), nullptr) != PT_OK)
+    const float *sum = Session::get().render_sum(world, cam, bg, max_x, max_y, samples_per_pixel, stats);
+    if (pt_film_finalize(sum, max_x, max_y, (uint32_t)samples_per_pixel, gamma.data(), nullptr) != PT_OK)
         throw scene_error("pt_film_finalize failed");
     for (size_t p = 0; p < (size_t)max_x * max_y; ++p) fb[p] = vec3(gamma[3 * p], gamma[3 * p + 1], gamma[3 * p + 2]);
 }

@@ -90,3 +90,22 @@ def test_shards_tile_the_sample_range(world, spp):
         distributed.shard("strong", world, world, spp)
     with pytest.raises(ValueError):
         distributed.shard("neither", 0, world, spp)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("spp,offset", [(8, 0), (64, 0), (100, 7), (1024, 0), (4096, 1 << 20), (4095, 3)])
+def test_the_library_group_cuts_samples_like_the_ranks_do(world, spp, offset):
+    """pt_group_render's own split (pt_group_shard, the C++ arithmetic its GPUs get their ranges from) tiles
+    [offset, offset + spp) and equals distributed.shard("strong"), the function bench.py's ranks call: a wrong range
+    there would duplicate or skip samples without any GPU test noticing (one GPU is all they have)."""
+    at = offset
+    for g in range(world):
+        off, n = api.group_shard(spp, offset, world, g)
+        want_off, want_n = distributed.shard("strong", g, world, spp)
+        assert (off, n) == (offset + want_off, want_n)
+        assert off == at and n >= 1
+        at += n
+    assert at == offset + spp
+    for bad in ((spp, offset, world, world), (spp, offset, world, -1), (spp, offset, 0, 0), (world - 1, offset, world, 0)):
+        with pytest.raises(api.PtError):
+            api.group_shard(*bad)

@@ -290,6 +290,35 @@ def test_far_field_hits_outside_the_exact_surface(ctx, kind, center):
         assert (excess > 0.05 * a[:, 3]).sum() > 50
 
 
+@pytest.mark.parametrize("slopes", [(0.05, 0.1, 0.3), (1.0, 3.0), (10.0, 20.0), (0.05, 1.0, 20.0)])
+@pytest.mark.parametrize("center", [(0.0, 0.0, 0.0), (5000.0, 300.0, -2000.0)])
+def test_rays_grazing_cones_from_afar(ctx, slopes, center):
+    """The adversarial case of the cone's quadratic (cone.h:101-129): thin / tall and flat / wide cones (radius / height
+    0.05 .. 20), near the origin and 5000 units from it, 10^5 rays that graze their sides from 10 .. 10^4 units away, a
+    third of them along the side itself where the leading coefficient cancels.  The rounding error of the
+    discriminant is amplified by 1 / sqrt(alpha), alpha = |a| / (|d_xz|^2 + tangens d_y^2), so accepted hits lie farther
+    outside the exact surface than for any other object.  Every answer outside the flagged set (alpha < 2^-6) must still
+    be the scan's, bit for bit, from the tree, from the GPU's own list scan, and the slope the tree gives its rays must
+    cover what these hits need with a margin (measured: at most 0.59 of it)."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    b, cones = util.cone_field(slopes, 200, center, rng)
+    ctx.upload(b.desc())
+    osc = util.oracle_scene(b)
+    o, d = util.grazing_cone_rays(cones, 100_000, rng)
+    ref = osc.trace(o, d)
+    ok = ref["nan_flag"] == 0
+    hit = ref["prim"] != api.NO_PRIM
+    assert (hit & ok).sum() > 40_000 and (hit & ~ok).sum() > 1000  # the regime is exercised, flagged rays included
+    for mode in (api.TRACE_BVH, api.TRACE_LINEAR):
+        got = ctx.trace(o, d, mode=mode)
+        bad = util.hits_equal(got, ref) & ok
+        assert not bad.any(), (slopes, center, mode, int(bad.sum()))
+    need = util.needed_cone_slope(b.arrays(), o, d, ref)
+    kappa = api.scene_ray_cone(b.desc())["kappa_max"]
+    assert need[ok].max() > 0.02 * kappa  # hits outside the exact volume do occur ...
+    assert need[ok].max() < 0.75 * kappa, (slopes, center, need[ok].max(), kappa)  # ... and the slope covers them with room
+
+
 def _noise_level_discriminant(arr, prim, o, d):
     """|discriminant| / half_b^2 of object `prim` for ray (o, d), in float64, after sphere.h:85-93, cylinder.h:96-106 and
     cone.h:101-113; inf for rects (no quadratic)."""
@@ -385,6 +414,39 @@ def test_odd_image_shapes(ctx, w, h, spp, depth):
     assert st["rays"] == rays and st["primary_rays"] == w * h * spp
     frac, rmse = _image_close(got, ref)
     assert frac <= (0.0 if w * h < 500 else 2e-3) and rmse < 2e-3
+
+
+@pytest.mark.parametrize("w,h,spp", [(4, 4, 3), (100, 75, 5), (9, 7, 300)])
+def test_small_frames_through_the_streaming_pipeline(ctx, w, h, spp):
+    """Frames of fewer pixels than one tile of the streaming pipeline's path numbering (64), and frames whose pixel
+    count is not a multiple of it, rendered with the scene in HBM (k_paths_stream): one band per pass whatever the
+    pixel count, the default pipeline's image bit for bit."""
+    ctx.upload(scenes.random_spheres_scene().desc())
+    base, st = ctx.render(w, h, spp, 50)
+    img, s2 = ctx.render(w, h, spp, 50, flags=api.RENDER_NO_LDS_SCENE)
+    assert s2["kernel"] == 2 and s2["rays"] == st["rays"]
+    assert s2["passes"] == (spp + 255) // 256  # one band: a pass per 256 samples, no tail band
+    assert np.array_equal(img.view(np.uint32), base.view(np.uint32))
+    with ctx.tuned(pipeline=1):  # the same kernel chosen by the tuning field
+        img, s3 = ctx.render(w, h, spp, 50, samples_per_pass=2)
+    assert s3["passes"] == (spp + 1) // 2 and np.array_equal(img.view(np.uint32), base.view(np.uint32))
+
+
+def test_render_into_a_pinned_host_buffer(ctx):
+    """pt_render fills pageable and page-locked (pt_host_alloc) buffers alike; the latter is written by the device
+    directly.  A frame larger than the staging chunks (4 MiB) goes through several of them."""
+    ctx.upload(scenes.default_scene().desc())
+    w, h = 800, 450  # 4.3 MB: two staging chunks
+    want, st = ctx.render(w, h, 2, 5)
+    with api.PinnedFilm(h, w) as film:
+        film.array[:] = -1.0
+        got, s2 = ctx.render(w, h, 2, 5, out=film.array)
+        assert s2["rays"] == st["rays"] and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    again, _ = ctx.render(w, h, 2, 5)
+    assert np.array_equal(again.view(np.uint32), want.view(np.uint32))
+    small, _ = ctx.render(31, 17, 2, 5)  # the kept device film is larger than this frame
+    ref, _ = ctx.render(31, 17, 2, 5, flags=api.RENDER_SPLIT_KERNELS)
+    assert np.array_equal(small.view(np.uint32), ref.view(np.uint32))
 
 
 def test_many_samples_span_several_passes_and_slices(ctx):
@@ -574,6 +636,20 @@ def test_group_of_one_gpu_goes_through_rccl(ctx):
         small, _ = g.render(64, 36, 2, 50)  # another frame size: the buffers are reallocated
         ref, _ = ctx.render(64, 36, 2, 50)
         assert np.array_equal(small.view(np.uint32), ref.view(np.uint32))
+        for _ in range(3):  # the workers are reused call after call
+            again, _ = g.render(64, 36, 2, 50)
+            assert np.array_equal(again.view(np.uint32), ref.view(np.uint32))
+        with api.PinnedFilm(36, 64) as film:  # a page-locked destination is written directly
+            got, _ = g.render(64, 36, 2, 50, out=film.array)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        import ctypes
+
+        ptr, sd = g.render_device(64, 36, 2, 50)  # the sum left on GPU 0: read it back with the runtime's own copy
+        hip = ctypes.CDLL(None)  # the HIP runtime the library uses (loaded into the global namespace by the binding)
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        back = np.zeros((36, 64, 3), dtype=np.float32)
+        assert ptr and hip.hipMemcpy(back.ctypes.data, ptr, back.nbytes, 2) == 0  # 2: device to host
+        assert sd["rays"] > 0 and np.array_equal(back.view(np.uint32), ref.view(np.uint32))
     with pytest.raises(api.PtError):
         api.Group([0, 0])  # one rank per GPU
 

@@ -74,3 +74,72 @@ def hits_equal(g, h):
     for f in ("n", "p"):
         bad |= hit & (g[f].view(np.uint32) != h[f].view(np.uint32)).any(axis=1)
     return bad
+
+
+def cone_field(slopes, n_per, center, rng, spread=60.0, size=(0.3, 1.3)):
+    """n_per cones of each radius / height ratio in `slopes`, heights in `size`, scattered over a cube of side `spread`
+    around `center`; returns (builder, [(centre, height, radius), ...])."""
+    center = np.asarray(center, dtype=np.float64)
+    b = scenes.SceneBuilder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    cones = []
+    for s in slopes:
+        for _ in range(n_per):
+            c = center + (rng.random(3) - 0.5) * spread
+            h = size[0] + rng.random() * (size[1] - size[0])
+            b.cone(tuple(c), h, s * h, m)
+            cones.append((c, h, s * h))
+    b.camera(tuple(center + [0, 0, 100]), tuple(center), (0, 1, 0), 40.0, 1.0, 0.0, 100.0)
+    return b, cones
+
+
+def grazing_cone_rays(cones, n, rng, dist_exp=(1.0, 4.0)):
+    """n rays that graze the sides of cones from 10^dist_exp units away: through a point of a cone's side along a
+    direction of its tangent plane there -- a third of them along the side's generator line, where the leading
+    coefficient of cone.h:108 cancels -- tilted out of the plane by 1e-3 .. 1e-1, with unnormalised directions of length
+    0.1 .. 300.  The regime in which the reference's fp32 quadratic accepts roots farthest outside the exact surface."""
+    o = np.zeros((n, 3))
+    d = np.zeros((n, 3))
+    for i in range(n):
+        c, h, r = cones[rng.integers(0, len(cones))]
+        y = rng.random() * h
+        rad = r * (1.0 - y / h)  # the apex is at the top: D = height - o.y + center.y, cone.h:105
+        phi = rng.random() * 2.0 * np.pi
+        q = c + np.array([rad * np.cos(phi), y, rad * np.sin(phi)])
+        nrm = np.array([np.cos(phi), r / h, np.sin(phi)])
+        nrm /= np.linalg.norm(nrm)
+        if rng.integers(0, 3) == 0:
+            v = np.array([-np.cos(phi) * r, h, -np.sin(phi) * r])
+            v *= (1.0 if rng.random() < 0.5 else -1.0) / np.linalg.norm(v)
+        else:
+            v = rng.standard_normal(3)
+            v -= nrm * (v @ nrm)
+            v /= np.linalg.norm(v)
+        v = v + nrm * rng.standard_normal() * 10.0 ** (-3.0 + 2.0 * rng.random())
+        v /= np.linalg.norm(v)
+        o[i] = q - v * 10.0 ** (dist_exp[0] + rng.random() * (dist_exp[1] - dist_exp[0]))
+        d[i] = v * 10.0 ** (rng.random() * 3.5 - 1.0)
+    return np.ascontiguousarray(o, dtype=np.float32), np.ascontiguousarray(d, dtype=np.float32)
+
+
+def needed_cone_slope(arrays, o, d, hits):
+    """For every hit of `hits` (oracle records): the slope kappa a tree needs so that the hit point lies within
+    kappa * (|d| t + the object's extent) + 2^-17 * (largest box coordinate) of the object's exact bounding volume on every
+    axis (the library's box padding and slab test); 0 where the point is inside.  Quadrics only (rects: 0)."""
+    prim = hits["prim"]
+    need = np.zeros(len(prim))
+    ok = prim != 0xFFFFFFFF
+    q = arrays["prim_param"][prim[ok]].astype(np.float64)
+    t = arrays["prim_type"][prim[ok]]
+    p = hits["p"][ok].astype(np.float64)
+    sph = t == api.SPHERE
+    r = np.where(sph, np.abs(q[:, 3]), np.abs(q[:, 4]))
+    h = np.where(sph, 0.0, q[:, 3])
+    lo = np.stack([q[:, 0] - r, np.where(sph, q[:, 1] - r, q[:, 1]), q[:, 2] - r], 1)
+    hi = np.stack([q[:, 0] + r, np.where(sph, q[:, 1] + r, q[:, 1] + h), q[:, 2] + r], 1)
+    m = np.maximum(np.abs(lo), np.abs(hi)).max(1)
+    excess = np.maximum(np.maximum(lo - p, p - hi), 0.0).max(1)
+    reach = np.linalg.norm(d[ok].astype(np.float64), axis=1) * np.abs(hits["t"][ok].astype(np.float64)) + r + np.abs(h)
+    quad = (t == api.SPHERE) | (t == api.CONE) | (t == api.CYLINDER)
+    need[ok] = np.where(quad, np.maximum(excess - m * 2.0 ** -17, 0.0) / np.maximum(reach, 1e-30), 0.0)
+    return need
