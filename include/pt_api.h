@@ -116,7 +116,8 @@ typedef struct pt_stats {
     uint32_t kernel;        /* which pipeline rendered the call: PT_KERNEL_* */
     uint32_t reserved;
 } pt_stats;
-enum { PT_KERNEL_PATHS = 1 /* k_paths */, PT_KERNEL_PATHS_STREAM = 2 /* k_paths_stream + k_film */, PT_KERNEL_SPLIT = 3 /* one launch per stage and bounce */ };
+enum { PT_KERNEL_PATHS = 1 /* k_paths */, PT_KERNEL_PATHS_STREAM = 2 /* k_paths_stream + k_film */, PT_KERNEL_SPLIT = 3 /* one launch per stage and bounce */,
+       PT_KERNEL_PATHS_RING = 4 /* k_paths_ring */ };
 
 typedef struct pt_context pt_context;
 
@@ -126,7 +127,8 @@ typedef struct pt_context pt_context;
 typedef struct pt_tuning {
     int32_t leaf_max;          /* objects per tree leaf, 1..8; applies from the next pt_scene_upload */
     int32_t wide_nodes;        /* 0 / 1: four-wide quantised nodes for scenes traversed from HBM; next pt_scene_upload */
-    int32_t pipeline;          /* 0 queue-based persistent workgroups (k_paths), 1 streaming lanes (k_paths_stream) */
+    int32_t pipeline;          /* 0 queue-based persistent workgroups, a slice at a time (k_paths); 1 streaming lanes (k_paths_stream); 2 queue-based with the
+                                  slices of a workgroup overlapped (k_paths_ring; scenes that fit on-chip memory, max_depth <= 2047) */
     int32_t lds_scene;         /* 0: never copy the scene into LDS */
     int32_t block;             /* threads per workgroup: 256 or 512 */
     int32_t workgroups_per_cu; /* 1..16 */
@@ -137,6 +139,7 @@ typedef struct pt_tuning {
     int32_t stream_phase;      /* 0..16: 0 both kinds of step per iteration; n: a leaf step once the lanes waiting for one outnumber n/4 of those at inner nodes (default 1) */
     int32_t stream_tile;       /* 64..4096, a multiple of 64: pixels per tile of k_paths_stream's path numbering */
     int32_t stream_run;        /* 64..65536: consecutive paths a wave takes at a time */
+    int32_t ring_low_water;    /* 0..2^22: k_paths_ring takes the next slice when fewer rays than this are queued (0: only when none is) */
     int32_t split_queue;       /* 0 / 1: k_paths on an LDS-resident scene of spheres queues the rays that head up (camera's up vector) apart from the others; the library's choice: scenes with a non-black background */
 } pt_tuning;
 void pt_tuning_default(pt_tuning *t); /* every field negative */

@@ -18,7 +18,7 @@ SPHERE, XY_RECT, XZ_RECT, YZ_RECT, CONE, CYLINDER = range(6)
 LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = range(4)
 TRACE_BVH, TRACE_LINEAR, TRACE_BVH_IN_SCENE, TRACE_BVH_GEOMETRIC = 0, 1, 2, 3
 RENDER_STAGE_TIMES, RENDER_NO_SORT, RENDER_COUNT_TESTS, RENDER_NO_LDS_SCENE, RENDER_SPLIT_KERNELS, RENDER_GEOMETRIC_CULL = 1, 2, 4, 8, 16, 32
-KERNEL_NAMES = {0: "-", 1: "k_paths", 2: "k_paths_stream", 3: "k_raygen/k_intersect/k_shade/k_film"}
+KERNEL_NAMES = {0: "-", 1: "k_paths", 2: "k_paths_stream", 3: "k_raygen/k_intersect/k_shade/k_film", 4: "k_paths_ring"}
 NOALLOC_SCRATCH_BYTES = 32 << 20
 NO_PRIM = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -79,7 +79,7 @@ class PtStats(C.Structure):
 
 
 TUNING_FIELDS = ("leaf_max", "wide_nodes", "pipeline", "lds_scene", "block", "workgroups_per_cu", "slice_paths", "slice_taper",
-                 "sort_by_material", "stream_serve_min", "stream_phase", "stream_tile", "stream_run", "split_queue")
+                 "sort_by_material", "stream_serve_min", "stream_phase", "stream_tile", "stream_run", "ring_low_water", "split_queue")
 
 
 class PtTuning(C.Structure):

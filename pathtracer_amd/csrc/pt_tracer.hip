@@ -1592,6 +1592,335 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_paths_ring: k_paths with the slices of a workgroup overlapped.  In k_paths a workgroup takes ONE slice through all
+// its bounces before it starts the next, and the bounces after the first few hold a handful of rays each: a bounce
+// costs the workgroup at least the latency of one wave's trace and shade whatever it holds, so the forty-odd tail
+// bounces of every slice are paid in full (14 % of all wave time at 64 samples per pixel on the random spheres, where a
+// slice is 32k paths; 49 % at 8, where a GPU's share of a strong-scaled frame makes slices of 5k).  Here the queue
+// never runs dry: whenever fewer than `low_water` rays are queued at the start of a generation, the workgroup takes
+// the next slice and its camera rays join the queue's survivors, so every generation but the last few of the launch
+// has several full chunks to work on and the stragglers of earlier slices ride along.  A path carries its own bounce
+// count and the ring slot of its slice (up to PT_RING slices are under way per workgroup, each with its own radiance
+// buffer and a count of unfinished paths in LDS); a slice whose count reaches zero is summed into the film in sample
+// order (main.cu:93) at the start of the next generation.  Same paths, same arithmetic, same film order as k_paths:
+// bit-identical images.
+// ---------------------------------------------------------------------------------------------
+#define PT_RING 16           // slices a workgroup may have under way
+#define PT_RING_LID_BITS 17  // a path's index within its slice (sample * pixels + pixel)
+#define PT_RING_SLOT_BITS 4
+#define PT_RING_MAX_DEPTH ((1 << (32 - PT_RING_LID_BITS - PT_RING_SLOT_BITS)) - 1) // the bounce count has the word's other 11 bits
+struct RingDev {
+    float4 *qA;   // [grid][2][qcap]
+    float4 *qB;
+    float2 *qC;
+    float *rad;   // [grid][PT_RING][cap * 3]
+    uint32_t qcap;      // entries per queue: low_water + cap
+    uint32_t cap;       // paths of the largest slice
+    uint32_t low_water; // a generation that starts with fewer queued rays than this takes the next slice as well
+    uint32_t n_slices;
+    const uint2 *extents; // [n_slices] (first pixel, pixels)
+    uint32_t *ticket;
+};
+
+template <bool COUNT, bool LDS, int BLOCK, int KIND, bool SPLIT = false, bool FLAT = false>
+__global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps, RingDev rg, float *__restrict__ rgb_sum, Counters *cnt)
+{
+    extern __shared__ float4 s_mem[];
+    __shared__ uint32_t s_out[4];                                  // [parity][0: queued from the front, 1: from the back (SPLIT)]
+    __shared__ uint32_t s_left[PT_RING], s_pix0[PT_RING], s_npix[PT_RING]; // per ring slot: unfinished paths, the slice's extent
+    __shared__ uint32_t s_open, s_fresh_slot, s_fresh_n, s_exhausted, s_chunk;
+    __shared__ uint32_t s_next_state, s_next_pix0, s_next_npix;    // the slice taken ahead of time: 0 none asked for, 1 a slice, 2 the table is used up
+    uint32_t *s_stack;
+    LdsSrc lsrc{nullptr, nullptr, sc.n_nodes, sc.n_prims, sc.cone};
+    if (LDS) {
+        s_stack = reinterpret_cast<uint32_t *>(lds_scene_copy<BLOCK>(sc, s_mem, lsrc));
+    } else {
+        s_stack = reinterpret_cast<uint32_t *>(s_mem);
+    }
+    GlobalSrc gsrc{sc.nodes, sc.prims, sc.cone};
+    const uint32_t qcap = rg.qcap, cap = rg.cap;
+    float4 *const qA = rg.qA + (size_t)blockIdx.x * 2 * qcap;
+    float4 *const qB = rg.qB + (size_t)blockIdx.x * 2 * qcap;
+    float2 *const qC = rg.qC + (size_t)blockIdx.x * 2 * qcap;
+    float *const rad = rg.rad + (size_t)blockIdx.x * PT_RING * 3 * cap;
+    const float t_min = 0.001f /* main.cu:54 */, t_max = PT_FLT_MAX /* commons.h:11 */;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long rays = 0;
+    uint32_t nb = 0, np = 0, nf = 0, nr = 0;
+    uint32_t extra_rays = 0; // rays traced from a lane without passing through a queue (the end of the launch)
+    ProfLanes prof;
+    unsigned long long sect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_last = kProf ? clock64() : 0;
+    auto mark = [&](int k) {
+        if (kProf) {
+            const long long now = clock64();
+            sect[k] += (unsigned long long)(now - t_last);
+            t_last = now;
+        }
+    };
+    // The next slice is asked for one generation ahead by one lane, which waits for the ticket and the slice's extent
+    // while the other waves work; the workgroup never waits for the counter in HBM.
+    auto take_ahead = [&]() {
+        const uint32_t ticket = atomicAdd(rg.ticket, 1u);
+        if (ticket < rg.n_slices) {
+            const uint2 e = rg.extents[ticket];
+            s_next_pix0 = e.x;
+            s_next_npix = e.y;
+            s_next_state = 1;
+        } else {
+            s_next_state = 2;
+        }
+    };
+    if (threadIdx.x == 0) {
+        s_out[0] = s_out[1] = s_out[2] = s_out[3] = 0;
+        s_open = 0; s_exhausted = 0; s_fresh_n = 0; s_fresh_slot = 0; s_chunk = 0;
+        take_ahead();
+    }
+    constexpr uint32_t LID_MASK = (1u << PT_RING_LID_BITS) - 1u, SLOT_MASK = (1u << PT_RING_SLOT_BITS) - 1u, ALL_OPEN = (1u << PT_RING) - 1u;
+    constexpr uint32_t BOUNCE_ONE = 1u << (PT_RING_LID_BITS + PT_RING_SLOT_BITS);
+    uint32_t cur = 0;
+    uint32_t summed = 0; // slices summed into the film during the last generation: their slots are free from this one on
+    long long t_drain = 0;
+    for (;;) {
+        __syncthreads(); // (A) the last generation's queue entries, radiance and counts are in place (the first time: the scene copy)
+        mark(4);
+        const uint32_t n_lo = s_out[2 * cur], n_hi = SPLIT ? s_out[2 * cur + 1] : 0u, n_queue = n_lo + n_hi;
+        const uint32_t open = s_open;
+        uint32_t closing = 0; // slices whose last path ended in the last generation
+        for (uint32_t m = open & ~summed; m; m &= m - 1u) {
+            const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+            if (s_left[k] == 0) closing |= 1u << k;
+        }
+        __syncthreads(); // (B) every thread has read what thread 0 changes now
+        if (threadIdx.x == 0) {
+            uint32_t now_open = open & ~summed, fresh = 0;
+            // the next slice joins when the queue runs low, into a slot that was free before this generation
+            if (!s_exhausted && n_queue < rg.low_water && open != ALL_OPEN) {
+                if (s_next_state == 2) {
+                    s_exhausted = 1;
+                } else {
+                    const uint32_t slot = (uint32_t)__ffs((int)~open) - 1u;
+                    s_pix0[slot] = s_next_pix0;
+                    s_npix[slot] = s_next_npix;
+                    fresh = s_next_npix * ps.samples;
+                    s_left[slot] = fresh;
+                    s_fresh_slot = slot;
+                    now_open |= 1u << slot;
+                    s_next_state = 0;
+                }
+            }
+            s_fresh_n = fresh;
+            s_open = now_open;
+            s_out[2 * (cur ^ 1u)] = s_out[2 * (cur ^ 1u) + 1] = 0;
+            s_chunk = 0;
+        }
+        __syncthreads(); // (C) thread 0's decisions are visible
+        mark(0);
+        const uint32_t fresh_n = s_fresh_n, fresh_slot = s_fresh_slot;
+        const uint32_t fresh_pix0 = s_pix0[fresh_slot], fresh_npix = s_npix[fresh_slot];
+        const uint32_t total = n_queue + fresh_n;
+        const bool last = total == 0 && s_exhausted != 0; // nothing queued, nothing left to take
+        // The end of the launch: no slice left to take and at most one chunk per wave queued.  Every wave then keeps the
+        // rays of its chunk in its lanes until the last of them has ended -- no queue, no barrier between their bounces.
+        // (A path of fifty bounces is fifty generations; with a handful of rays each, a generation is all latency.)
+        const bool drain = s_exhausted != 0 && total <= (uint32_t)BLOCK;
+        if (threadIdx.x == BLOCK - 1 && fresh_n) take_ahead(); // (the last wave's: with chunks dealt out on demand it just takes fewer)
+        const float4 *inA = qA + cur * qcap, *inB = qB + cur * qcap;
+        const float2 *inC = qC + cur * qcap;
+        float4 *outA = qA + (cur ^ 1u) * qcap, *outB = qB + (cur ^ 1u) * qcap;
+        float2 *outC = qC + (cur ^ 1u) * qcap;
+        uint32_t *const out_cnt = &s_out[2 * (cur ^ 1u)];
+        // Chunks of 64 rays are dealt out to the waves on demand (one LDS atomic each): rays differ several-fold in cost, and
+        // with a fixed share per wave the workgroup would wait at the end of every generation for the wave that drew the dearest.
+        for (;;) {
+            uint32_t c0 = 0;
+            if (lane == 0) c0 = atomicAdd(&s_chunk, 64u);
+            c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+            if (c0 >= total) break;
+            const uint32_t i = c0 + lane;
+            const bool valid = i < total;
+            Ray r;
+            r.o = V(0.0f, 0.0f, 0.0f);
+            r.d = V(0.0f, 0.0f, 0.0f);
+            v3 T = V(1.0f, 1.0f, 1.0f);
+            uint32_t idw = 0; // path index within its slice | ring slot | bounces so far
+            HitResult h;
+            h.t = 0.0f;
+            h.slot = PT_NO_PRIM;
+            bool valid_now = valid;
+            if (valid) {
+                if (i < n_queue) {
+                    const uint32_t qi = SPLIT && i >= n_lo ? qcap - 1u - (i - n_lo) : i; // (the rays queued from the back)
+                    const float4 A = inA[qi], B = inB[qi];
+                    const float2 C = inC[qi];
+                    idw = __float_as_uint(A.w);
+                    r.o = V(A.x, A.y, A.z);
+                    r.d = V(B.x, B.y, B.z);
+                    T = V(B.w, C.x, C.y);
+                } else {
+                    // the new slice's camera rays, numbered sample-fast: a wave starts with the samples of one or a few pixels
+                    const uint32_t f = i - n_queue;
+                    const uint32_t pl = f / ps.samples, s = f - pl * ps.samples;
+                    idw = (s * fresh_npix + pl) | (fresh_slot << PT_RING_LID_BITS);
+                    r = camera_ray(sc.cam, ps, fresh_pix0 + pl, ps.sample_base + s);
+                }
+            }
+            mark(1);
+            bool survive = false;
+            float4 oA, oB;
+            float2 oC;
+            for (;;) { // (once, except at the end of the launch)
+            h.slot = PT_NO_PRIM;
+            if (valid_now) {
+                bool need_exact;
+                const int32_t root_ref = FLAT ? sc.root_ref : 0;
+                if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK, LdsSrc, FLAT>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
+                else h = bvh_nearest<COUNT, KIND, BLOCK, GlobalSrc, FLAT>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
+                if (need_exact) { // resolved on the list-order records; the top bit of the slot says which array it indexes
+                    h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max);
+                    if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;
+                    nf++;
+                }
+            }
+            mark(2);
+            // main.cu:54-64 for the traced ray, then compaction of the wave's survivors into the next queue
+            survive = false;
+            if (valid_now) {
+                const uint32_t lid = idw & LID_MASK, slot = (idw >> PT_RING_LID_BITS) & SLOT_MASK;
+                v3 result;
+                if (h.slot == PT_NO_PRIM) {
+                    result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
+                } else {
+                    PrimRec q;
+                    if (LDS && (KIND == PT_KIND_SPHERES || (h.slot & 0x80000000u) == 0)) {
+                        float4 w0, w1;
+                        lsrc.prim(h.slot, w0, w1);
+                        q.p[0] = w0.x; q.p[1] = w0.y; q.p[2] = w0.z; q.p[3] = w0.w; q.p[4] = w1.x; q.p[5] = w1.y;
+                        q.meta = __float_as_uint(w1.z);
+                        q.id = __float_as_uint(w1.w);
+                    } else {
+                        q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
+                    }
+                    const uint32_t npix = s_npix[slot];
+                    const uint32_t s = lid / npix, pl = lid - s * npix;
+                    Ray nray;
+                    v3 nT;
+                    if (kProf) prof.tick(3);
+                    survive = shade_hit<KIND == PT_KIND_SPHERES>(sc.mats, ps, r, T, s_pix0[slot] + pl, ps.sample_base + s, (int32_t)(idw >> (PT_RING_LID_BITS + PT_RING_SLOT_BITS)), q, h.t,
+                                                                 nray, nT, result, &prof);
+                    if (survive) {
+                        oA = make_float4(nray.o.x, nray.o.y, nray.o.z, __uint_as_float(idw + BOUNCE_ONE));
+                        oB = make_float4(nray.d.x, nray.d.y, nray.d.z, nT.x);
+                        oC = make_float2(nT.y, nT.z);
+                    }
+                }
+                if (!survive) {
+                    float *rk = rad + ((size_t)slot * cap + lid) * 3;
+                    rk[0] = result.x;
+                    rk[1] = result.y;
+                    rk[2] = result.z;
+                    atomicSub(&s_left[slot], 1u);
+                }
+            }
+            if (!drain || __ballot(survive) == 0ull) break;
+            // the end of the launch: the survivors go on from their lanes
+            valid_now = survive;
+            if (survive) {
+                r.o = V(oA.x, oA.y, oA.z);
+                r.d = V(oB.x, oB.y, oB.z);
+                T = V(oB.w, oC.x, oC.y);
+                idw = __float_as_uint(oA.w);
+                extra_rays++;
+            }
+            }
+            if (SPLIT) { // as in k_paths: rays that head up (camera's up vector) from the back of the next queue, the others from its front
+                const bool up = oB.x * sc.cam.v[0] + oB.y * sc.cam.v[1] + oB.z * sc.cam.v[2] > 0.0f;
+                const unsigned long long m0 = __ballot(survive && !up), m1 = __ballot(survive && up);
+                if (m0 | m1) {
+                    const unsigned long long mine = up ? m1 : m0;
+                    const uint32_t pre = lane_prefix(mine);
+                    uint32_t pos0 = 0;
+                    if (survive && pre == 0) pos0 = atomicAdd(&out_cnt[up ? 1 : 0], (uint32_t)__popcll(mine));
+                    const uint32_t p0 = __shfl(pos0, m0 ? __ffsll((long long)m0) - 1 : 0, 64), p1 = __shfl(pos0, m1 ? __ffsll((long long)m1) - 1 : 0, 64);
+                    if (survive) {
+                        const uint32_t at = up ? qcap - 1u - (p1 + pre) : p0 + pre;
+                        outA[at] = oA;
+                        outB[at] = oB;
+                        outC[at] = oC;
+                    }
+                }
+            } else {
+                const unsigned long long mask = __ballot(survive);
+                if (mask) {
+                    const uint32_t pre = lane_prefix(mask);
+                    uint32_t pos0 = 0;
+                    if (survive && pre == 0) pos0 = atomicAdd(&out_cnt[0], (uint32_t)__popcll(mask));
+                    pos0 = __shfl(pos0, __ffsll((long long)mask) - 1, 64);
+                    if (survive) {
+                        outA[pos0 + pre] = oA;
+                        outB[pos0 + pre] = oB;
+                        outC[pos0 + pre] = oC;
+                    }
+                }
+            }
+            mark(3);
+        }
+        // film: col += ray_color(...) in sample order (main.cu:93) for the pixels of the slices that finished in the last
+        // generation, by every wave as it runs out of chunks (their slots stay taken until the next generation)
+        for (uint32_t m = closing; m; m &= m - 1u) {
+            const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+            const uint32_t pix0 = s_pix0[k], npix = s_npix[k];
+            const float *rk = rad + (size_t)k * 3 * cap;
+            for (uint32_t pl = threadIdx.x; pl < npix; pl += BLOCK) {
+                const size_t px = (size_t)(pix0 + pl) * 3;
+                float r = rgb_sum[px], g = rgb_sum[px + 1], bl = rgb_sum[px + 2];
+                for (uint32_t s = 0; s < ps.samples; ++s) {
+                    const uint32_t lid = s * npix + pl;
+                    r += rk[3 * lid];
+                    g += rk[3 * lid + 1];
+                    bl += rk[3 * lid + 2];
+                }
+                rgb_sum[px] = r;
+                rgb_sum[px + 1] = g;
+                rgb_sum[px + 2] = bl;
+            }
+        }
+        mark(5);
+        if (kProf && s_exhausted) { // diagnostic build: generations after the last slice was taken, and how many rays they held
+            if (t_drain == 0) t_drain = clock64();
+            if (threadIdx.x == 0) { sect[7] += 1; prof.lanes[5] += total; }
+        }
+        if (last) break; // (every slice still open had no path left: summed just now or a generation ago)
+        if (threadIdx.x == 0) rays += total;
+        summed = closing;
+        cur ^= 1u;
+    }
+    if (kProf && t_drain) sect[6] += (unsigned long long)(clock64() - t_drain);
+    if (kProf) {
+        for (int k = 0; k < 6; ++k) {
+            const unsigned long long a = wave_sum_u32(prof.lanes[k]), b2 = wave_sum_u32(prof.slots[k]);
+            if (lane == 0) { atomicAdd(&cnt->lanes[k], a); atomicAdd(&cnt->slots[k], b2); }
+        }
+        if (lane == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&cnt->sect[k], sect[k]);
+    }
+    {
+        const unsigned long long ex = wave_sum_u32(extra_rays);
+        if (lane == 0) rays += ex;
+    }
+    if (lane == 0 && rays) atomicAdd(&cnt->rays, rays);
+    if (COUNT) {
+        unsigned long long sb = wave_sum_u32(nb), sp = wave_sum_u32(np);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&cnt->box_tests, sb);
+            atomicAdd(&cnt->prim_tests, sp);
+        }
+    }
+    if (nf) atomicAdd(&cnt->exact_fallbacks, (unsigned long long)nf);
+    if (nr) atomicAdd(&cnt->exact_replays, (unsigned long long)nr);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_paths_stream: the slice pipeline for scenes traversed from HBM, where every traversal step waits on
 // memory and rays differ widely in cost (1..5000 node visits on the 1M-sphere scene).  In k_paths a wave
 // traces 64 rays and waits for the slowest of them, and a workgroup waits at the end of every bounce for
@@ -2069,6 +2398,11 @@ struct pt_context {
     float2 *d_sC = nullptr;
     float *d_srad = nullptr;
     uint32_t *d_ticket = nullptr;
+    // k_paths_ring workspace: queues [grid][2][qcap], radiance [grid][PT_RING][cap * 3]
+    size_t cap_ring_queue = 0, cap_ring_rad = 0; // entries, paths
+    float4 *d_gA = nullptr, *d_gB = nullptr;
+    float2 *d_gC = nullptr;
+    float *d_grad = nullptr;
     uint2 *d_extents = nullptr; // slice table of the last frame shape
     size_t cap_extents = 0;
     uint32_t ext_key[4] = {0, 0, 0, 0}, n_extents = 0;
@@ -2169,7 +2503,7 @@ extern "C" pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t)
     const char *bad = nullptr;
     if (!in(t->leaf_max, 1, 8)) bad = "leaf_max (1..8)";
     else if (!in(t->wide_nodes, 0, 1)) bad = "wide_nodes (0, 1)";
-    else if (!in(t->pipeline, 0, 1)) bad = "pipeline (0, 1)";
+    else if (!in(t->pipeline, 0, 2)) bad = "pipeline (0, 1, 2)";
     else if (!in(t->lds_scene, 0, 1)) bad = "lds_scene (0, 1)";
     else if (!(t->block < 0 || t->block == 256 || t->block == 512)) bad = "block (256, 512)";
     else if (!in(t->workgroups_per_cu, 1, 16)) bad = "workgroups_per_cu (1..16)";
@@ -2181,6 +2515,7 @@ extern "C" pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t)
     else if (!(t->stream_tile < 0 || (t->stream_tile >= 64 && t->stream_tile <= 4096 && t->stream_tile % 64 == 0))) bad = "stream_tile (64..4096, a multiple of 64)";
     else if (!in(t->stream_run, 64, 65536)) bad = "stream_run (64..65536)";
     else if (!in(t->split_queue, 0, 1)) bad = "split_queue (0, 1)";
+    else if (!in(t->ring_low_water, 0, 1 << 22)) bad = "ring_low_water (0..2^22)";
     if (bad) return fail(ctx, PT_ERR_INVALID, std::string("pt_tuning: out of range: ") + bad);
     ctx->tune = *t;
     if (hipSetDevice(ctx->device) == hipSuccess) make_stream_plan(ctx);
@@ -2213,6 +2548,7 @@ extern "C" void pt_context_destroy(pt_context *ctx)
     free_workspace(ctx);
     hipFree(ctx->d_nactive); hipFree(ctx->d_cnt);
     hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad); hipFree(ctx->d_ticket);
+    hipFree(ctx->d_gA); hipFree(ctx->d_gB); hipFree(ctx->d_gC); hipFree(ctx->d_grad);
     hipFree(ctx->d_ro); hipFree(ctx->d_rd); hipFree(ctx->d_rh);
     hipFree(ctx->d_film);
     if (ctx->h_film) hipHostFree(ctx->h_film);
@@ -2684,6 +3020,32 @@ static void launch_paths(pt_context *ctx, const SceneDev &scene, hipStream_t str
 #undef PT_LAUNCH_PATHS
 }
 
+template <bool COUNT>
+static void launch_ring(pt_context *ctx, const SceneDev &scene, hipStream_t stream, int block, bool split, uint32_t grid, size_t lds_bytes, const PassDev &ps,
+                        const RingDev &rg, float *d_rgb_sum)
+{
+    const int kind = ctx->kind;
+#define PT_LAUNCH_RING(B, K, SP, FL) hipLaunchKernelGGL((k_paths_ring<COUNT, true, B, K, SP, FL>), dim3(grid), dim3(B), lds_bytes, stream, scene, ps, rg, d_rgb_sum, ctx->d_cnt)
+#define PT_LAUNCH_RING_B(K, SP, FL)              \
+    do {                                         \
+        if (block == 256) PT_LAUNCH_RING(256, K, SP, FL); \
+        else PT_LAUNCH_RING(512, K, SP, FL);     \
+    } while (0)
+    if (!COUNT && scene.root_ref < 0 && kind != PT_KIND_SPHERES) { // a scene of one leaf: the kernels without tree code
+        if (kind == PT_KIND_ANY) PT_LAUNCH_RING_B(PT_KIND_ANY, false, true);
+        else PT_LAUNCH_RING_B(PT_KIND_NO_CONES, false, true);
+    } else if (kind == PT_KIND_SPHERES) {
+        if (split) PT_LAUNCH_RING_B(PT_KIND_SPHERES, true, false);
+        else PT_LAUNCH_RING_B(PT_KIND_SPHERES, false, false);
+    } else if (kind == PT_KIND_NO_CONES) {
+        PT_LAUNCH_RING_B(PT_KIND_NO_CONES, false, false);
+    } else {
+        PT_LAUNCH_RING_B(PT_KIND_ANY, false, false);
+    }
+#undef PT_LAUNCH_RING_B
+#undef PT_LAUNCH_RING
+}
+
 // The k_paths_stream instance for a launch shape.
 static const void *stream_kernel_for(bool count, int block, int kind, bool wide)
 {
@@ -2699,9 +3061,13 @@ static const void *stream_kernel_for(bool count, int block, int kind, bool wide)
 }
 
 // Launch shape of the path kernels for the installed scene: which pipeline, workgroup size, LDS use, resident grid.
+#ifndef PT_DEFAULT_LDS_PIPELINE
+#define PT_DEFAULT_LDS_PIPELINE 2 // which kernel renders a scene that fits LDS unless pt_tuning.pipeline says otherwise: 0 k_paths, 2 k_paths_ring
+#endif
 struct PathsShape {
     int block;
     bool lds, sort, stream, wide;
+    bool ring;                 // k_paths_ring (slices overlapped within a workgroup) instead of k_paths
     size_t lds_bytes;          // k_paths: traversal stacks (+ the scene copy)
     size_t stream_stack_bytes; // k_paths_stream: traversal stacks
     uint32_t grid_max;         // resident workgroups
@@ -2732,13 +3098,15 @@ static PathsShape paths_shape(pt_context *ctx, uint32_t flags, bool count, bool 
     ps.lds = want_lds && !force_stream && scene_bytes + stack_bytes <= 64 * 1024;
     ps.lds_bytes = stack_bytes + (ps.lds ? scene_bytes : 0);
     // scenes traversed from HBM take the streaming kernel (pt_tuning.pipeline overrides)
-    ps.stream = force_stream || (!ps.sort && tuned(tu.pipeline, ps.lds ? 0 : 1) != 0);
+    const int pipeline = tuned(tu.pipeline, ps.lds ? PT_DEFAULT_LDS_PIPELINE : 1);
+    ps.ring = !force_stream && !ps.sort && ps.lds && pipeline == 2; // (scenes that do not fit LDS: the streaming kernel instead)
+    ps.stream = force_stream || (!ps.sort && pipeline != 0 && !ps.ring);
     ps.wide = ps.stream && sc.wide != nullptr;
     // the wide traversal's stack; the exact replay of cone scenes walks the binary tree on the same stack
     ps.stream_stack_bytes = ps.wide ? (size_t)std::max(sc.wide_stack_cap, ctx->has_cones ? sc.stack_cap : 0u) * block * 4 : stack_bytes;
     int per_cu = tuned(tu.workgroups_per_cu, 0);
     if (per_cu <= 0) {
-        const size_t static_lds = 64 + (ps.sort ? (size_t)block * 10 + 64 : 0); // s_hit, s_perm, s_bin, counters
+        const size_t static_lds = 64 + (ps.sort ? (size_t)block * 10 + 64 : 0) + (ps.ring ? 12 * PT_RING + 32 : 0); // s_hit, s_perm, s_bin, counters; the ring's slots
         const size_t lds_used = (ps.stream ? ps.stream_stack_bytes : ps.lds_bytes) + static_lds;
         const int waves_per_simd = ps.stream ? PT_STREAM_WAVES : 6; // the kernels' register budgets
         per_cu = std::min<int>(waves_per_simd * 4 * 64 / block, (int)((160 * 1024) / std::max<size_t>(lds_used, 1)));
@@ -2896,13 +3264,22 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     // Paths per slice: 32k amortises a slice's ramp-down best, but a frame needs a few slices per resident
     // workgroup to balance (a slice's cost varies several-fold with what its pixels see).
     const uint64_t total_paths = (uint64_t)n_pixels * pr->spp;
-    const uint32_t balanced = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(4096, total_paths / (4ull * grid_max)));
-    const uint32_t target = (uint32_t)tuned(ctx->tune.slice_paths, (int)balanced);
-    uint32_t spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
-    spass = std::min(spass, pr->spp);
-    uint32_t pix = std::max(64u, (target / spass) & ~63u);
-    const uint32_t cap = pix * spass;
-    if ((uint64_t)cap * 3 >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one slice");
+    bool ring = sh.ring && pr->max_depth <= PT_RING_MAX_DEPTH;
+    uint32_t spass = 0, pix = 0, cap = 0;
+    for (;;) {
+        // k_paths_ring keeps its queue filled across slices, so its slices only have to be small enough to balance the end
+        // of the frame (16 per resident workgroup) and large enough to be worth a ticket
+        const uint32_t balanced = ring ? (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(2048, total_paths / (16ull * grid_max)))
+                                       : (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(4096, total_paths / (4ull * grid_max)));
+        const uint32_t target = (uint32_t)tuned(ctx->tune.slice_paths, (int)balanced);
+        spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
+        spass = std::min(spass, pr->spp);
+        pix = std::max(64u, (target / spass) & ~63u);
+        if ((uint64_t)pix * spass * 3 >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one slice");
+        cap = pix * spass;
+        if (ring && cap > (1u << PT_RING_LID_BITS)) { ring = false; continue; } // a slice too large for the ring's path index: k_paths
+        break;
+    }
     PT_HIP(ctx, hipSetDevice(ctx->device));
     // Slices: full-sized ones while plenty of work is left, then sizes falling with what remains (what is
     // left / resident workgroups, never under a quarter of the full size), so that the workgroups finish the
@@ -2933,7 +3310,29 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const uint32_t n_slices = ctx->n_extents;
     const uint32_t grid = std::min(grid_max, n_slices);
 
-    const size_t need = (size_t)grid * cap;
+    // k_paths_ring: a new slice joins a queue of fewer than low_water rays
+    // (four chunks per wave: random spheres 13.6 ms at 1024 .. 4096 against 13.9 at 512 and 14.5 at 16384, where every generation
+    // takes a slice; the Cornell box is flat from 256 to 1024)
+    const uint32_t low_water = std::max(1u, (uint32_t)tuned(ctx->tune.ring_low_water, 4 * block));
+    const uint32_t qcap = low_water + cap;
+    if (ring) {
+        const size_t need_q = (size_t)grid * 2 * qcap, need_r = (size_t)grid * PT_RING * cap;
+        if (need_q > ctx->cap_ring_queue) {
+            hipFree(ctx->d_gA); hipFree(ctx->d_gB); hipFree(ctx->d_gC);
+            ctx->d_gA = ctx->d_gB = nullptr; ctx->d_gC = nullptr; ctx->cap_ring_queue = 0;
+            PT_HIP(ctx, hipMalloc(&ctx->d_gA, need_q * sizeof(float4)));
+            PT_HIP(ctx, hipMalloc(&ctx->d_gB, need_q * sizeof(float4)));
+            PT_HIP(ctx, hipMalloc(&ctx->d_gC, need_q * sizeof(float2)));
+            ctx->cap_ring_queue = need_q;
+        }
+        if (need_r > ctx->cap_ring_rad) {
+            hipFree(ctx->d_grad);
+            ctx->d_grad = nullptr; ctx->cap_ring_rad = 0;
+            PT_HIP(ctx, hipMalloc(&ctx->d_grad, need_r * 3 * sizeof(float)));
+            ctx->cap_ring_rad = need_r;
+        }
+    }
+    const size_t need = ring ? 0 : (size_t)grid * cap;
     if (need > ctx->cap_slice_paths) {
         hipFree(ctx->d_sA); hipFree(ctx->d_sB); hipFree(ctx->d_sC); hipFree(ctx->d_srad);
         ctx->d_sA = ctx->d_sB = nullptr; ctx->d_sC = nullptr; ctx->d_srad = nullptr; ctx->cap_slice_paths = 0;
@@ -2966,7 +3365,13 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         ps.sample_base = pr->sample_offset + done;
         PT_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, sizeof(uint32_t), stream));
         tm.begin(1);
-        if (count) launch_paths<true>(ctx, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);
+        if (ring) {
+            RingDev rg;
+            rg.qA = ctx->d_gA; rg.qB = ctx->d_gB; rg.qC = ctx->d_gC; rg.rad = ctx->d_grad;
+            rg.qcap = qcap; rg.cap = cap; rg.low_water = low_water; rg.n_slices = n_slices; rg.extents = ctx->d_extents; rg.ticket = ctx->d_ticket;
+            if (count) launch_ring<true>(ctx, scene, stream, block, split, grid, lds_bytes, ps, rg, d_rgb_sum);
+            else launch_ring<false>(ctx, scene, stream, block, split, grid, lds_bytes, ps, rg, d_rgb_sum);
+        } else if (count) launch_paths<true>(ctx, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);
         else launch_paths<false>(ctx, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);
         tm.end();
     }
@@ -2985,12 +3390,14 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         stats->exact_replays = h.exact_replays;
         stats->launches_intersect = n_passes;
         stats->passes = n_passes;
-        stats->kernel = PT_KERNEL_PATHS;
+        stats->kernel = ring ? PT_KERNEL_PATHS_RING : PT_KERNEL_PATHS;
         if (kProf) {
             static const char *names[6] = {"slice setup", "ray fetch / camera", "trace", "shade + emit", "bounce barriers", "film"};
             unsigned long long tot = 0;
             for (int k = 0; k < 6; ++k) tot += h.sect[k];
             for (int k = 0; k < 6; ++k) fprintf(stderr, "[prof] %-20s %5.1f %% of wave time\n", names[k], 100.0 * (double)h.sect[k] / (double)std::max(tot, 1ull));
+            if (ring) fprintf(stderr, "[prof] after the last slice was taken: %.1f %% of wave time, %.1f generations per workgroup holding %.0f rays in all\n",
+                              100.0 * (double)h.sect[6] / (double)std::max(tot, 1ull), (double)h.sect[7] / (double)grid, (double)h.lanes[5] / (double)grid);
             static const char *ln[6] = {"node visits", "object tests", "sphere-sample tries", "shade calls", "sphere roots", "-"};
             for (int k = 0; k < 5; ++k)
                 fprintf(stderr, "[prof] %-20s lanes %llu slots %llu utilisation %.1f %%\n", ln[k], h.lanes[k], h.slots[k], 100.0 * (double)h.lanes[k] / (double)std::max(h.slots[k], 1ull));

@@ -90,7 +90,14 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth):
                  dict(hbm=1, block=512), dict(hbm=1, pipeline=0),
                  # node and leaf steps in every iteration / by plain majority; short runs of paths per wave
                  dict(hbm=1, stream_phase=0), dict(hbm=1, stream_phase=4), dict(hbm=1, stream_run=64),
-                 dict(pipeline=1)):
+                 dict(pipeline=1),
+                 # the queue-based kernel that takes one slice at a time (k_paths; the default, k_paths_ring, overlaps them)
+                 dict(pipeline=0), dict(pipeline=0, block=256), dict(pipeline=0, split_queue=0), dict(pipeline=0, split_queue=1),
+                 dict(pipeline=0, slice_paths=1000000),
+                 # k_paths_ring taking a new slice only when the queue is empty, with every slice it can hold under way at once,
+                 # with small workgroups, and with slices too large for its path index (which k_paths renders)
+                 dict(pipeline=2), dict(pipeline=2, ring_low_water=0), dict(pipeline=2, ring_low_water=1 << 20, slice_paths=256),
+                 dict(pipeline=2, block=256, slice_paths=1024), dict(pipeline=2, split_queue=0), dict(pipeline=2, slice_paths=1 << 18)):
         tune = dict(tune)
         flags = api.RENDER_NO_LDS_SCENE if tune.pop("hbm", None) else 0
         with ctx.tuned(**tune):

@@ -29,7 +29,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(api.PtCamera) == 22 * 4
     assert api.HIT_DTYPE.itemsize == 40 and api.NODE_DTYPE.itemsize == 64
     assert C.sizeof(api.PtRenderParams) == 40 and C.sizeof(api.PtStats) == 112
-    assert C.sizeof(api.PtTuning) == 14 * 4 == 4 * len(api.TUNING_FIELDS)
+    assert C.sizeof(api.PtTuning) == 15 * 4 == 4 * len(api.TUNING_FIELDS)
 
 
 def test_context_create_fails_cleanly_without_a_gpu():
