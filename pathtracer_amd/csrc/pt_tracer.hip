@@ -146,9 +146,10 @@ struct BoxRay {
     float afx, afy, afz, cfx, cfy, cfz; // constants applied to the far planes
     uint32_t sx, sy, sz;                // byte offset of the near pair within an axis quad: 0 (lo planes near) or 8
     float eps;                          // absolute error bound of a plane distance (rounding of o * inv)
+    float eps_far;                      // 2^-22 * the largest ratio of an axis' far constants to its near ones, (1 + w) / (1 - w): see the four-wide step
 };
 
-PT_DI void box_ray_axis(float o, float d, float kd, float &a_n, float &c_n, float &a_f, float &c_f, uint32_t &near_off, float &cmax)
+PT_DI void box_ray_axis(float o, float d, float kd, float &a_n, float &c_n, float &a_f, float &c_f, uint32_t &near_off, float &cmax, float &kmax)
 {
     // A component of exactly (or nearly) zero would make the reciprocal infinite; the box test sees such
     // a ray as very slightly tilted instead (2^-60), which keeps every distance finite.  Only the pruning
@@ -166,6 +167,7 @@ PT_DI void box_ray_axis(float o, float d, float kd, float &a_n, float &c_n, floa
         a_f = inv * f;
         c_f = no * f;
         cmax = fmaxf(cmax, fabsf(c_f));
+        kmax = fmaxf(kmax, (1.0f + w) * f);
     } else { // the cone is wider than the ray's progress along this axis: no far bound from it
         a_f = 0.0f;
         c_f = 3.0e38f;
@@ -193,11 +195,12 @@ PT_DI BoxRay make_box_ray(const Ray &r, float kappa)
     BoxRay b;
     // |d| from the hardware sqrt, rounded up: kd only has to be an upper bound of kappa |d|
     const float kd = kappa * __builtin_amdgcn_sqrtf(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z) * 1.000001f;
-    float cmax = 0.0f;
-    box_ray_axis(r.o.x, r.d.x, kd, b.anx, b.cnx, b.afx, b.cfx, b.sx, cmax);
-    box_ray_axis(r.o.y, r.d.y, kd, b.any, b.cny, b.afy, b.cfy, b.sy, cmax);
-    box_ray_axis(r.o.z, r.d.z, kd, b.anz, b.cnz, b.afz, b.cfz, b.sz, cmax);
+    float cmax = 0.0f, kmax = 1.0f;
+    box_ray_axis(r.o.x, r.d.x, kd, b.anx, b.cnx, b.afx, b.cfx, b.sx, cmax, kmax);
+    box_ray_axis(r.o.y, r.d.y, kd, b.any, b.cny, b.afy, b.cfy, b.sy, cmax, kmax);
+    box_ray_axis(r.o.z, r.d.z, kd, b.anz, b.cnz, b.afz, b.cfz, b.sz, cmax, kmax);
     b.eps = cmax * (1.0f / 4194304.0f); // 2^-22 * max|C|: twice the rounding bound of C and of bound * A near the origin
+    b.eps_far = kmax * (1.00001f / 4194304.0f);
     return b;
 }
 
@@ -1622,6 +1625,26 @@ struct RingDev {
     uint32_t *ticket;
 };
 
+// Adds a finished slice to the film: film[e] += the samples of rad[sample][e], e = 3 * pixel + channel, one after the
+// other in sample order (main.cu:93).  A call of its own, so that its registers are not the path loop's.
+static __device__ __attribute__((noinline)) void ring_film(const float *__restrict__ rk, float *__restrict__ film, uint32_t n3, uint32_t samples, uint32_t block)
+{
+    for (uint32_t e = threadIdx.x; e < n3; e += block) {
+        float acc = film[e];
+        const float *src = rk + e;
+        uint32_t s = 0;
+        for (; s + 8 <= samples; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * n3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; s < samples; ++s) acc += src[(size_t)s * n3];
+        film[e] = acc;
+    }
+}
+
 template <bool COUNT, bool LDS, int BLOCK, int KIND, bool SPLIT = false, bool FLAT = false>
 __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps, RingDev rg, float *__restrict__ rgb_sum, Counters *cnt)
 {
@@ -1869,21 +1892,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
         // generation, by every wave as it runs out of chunks (their slots stay taken until the next generation)
         for (uint32_t m = closing; m; m &= m - 1u) {
             const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
-            const uint32_t pix0 = s_pix0[k], npix = s_npix[k];
-            const float *rk = rad + (size_t)k * 3 * cap;
-            for (uint32_t pl = threadIdx.x; pl < npix; pl += BLOCK) {
-                const size_t px = (size_t)(pix0 + pl) * 3;
-                float r = rgb_sum[px], g = rgb_sum[px + 1], bl = rgb_sum[px + 2];
-                for (uint32_t s = 0; s < ps.samples; ++s) {
-                    const uint32_t lid = s * npix + pl;
-                    r += rk[3 * lid];
-                    g += rk[3 * lid + 1];
-                    bl += rk[3 * lid + 2];
-                }
-                rgb_sum[px] = r;
-                rgb_sum[px + 1] = g;
-                rgb_sum[px + 2] = bl;
-            }
+            // one thread per (pixel, colour channel): the samples of a sum are still added one after the other, in sample
+            // order, but three times as many threads work and the loads of eight samples are under way together
+            ring_film(rad + (size_t)k * 3 * cap, rgb_sum + (size_t)s_pix0[k] * 3, 3u * s_npix[k], ps.samples, BLOCK);
         }
         mark(5);
         if (kProf && s_exhausted) { // diagnostic build: generations after the last slice was taken, and how many rays they held
@@ -2170,6 +2181,34 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     const uint32_t qnz = br.sz ? hiz : loz, qfz = br.sz ? loz : hiz;
                     uint32_t key[4]; // distance at which the ray's cone enters the child's box (its low two bits give way to the child's slot)
                     int32_t cr[4] = {__float_as_int(w2.z), __float_as_int(w2.w), __float_as_int(w3.x), __float_as_int(w3.y)};
+#ifdef PT_WIDE_FOLD
+                    // The node's grid folded into the slab constants: a plane distance is (origin + q step) A + C = q (step A) + (origin A + C),
+                    // one FMA per plane after twelve operations per node instead of two per plane.  step is a power of two, so step A is
+                    // exact; origin A + C is rounded once more than in the unfolded form, by at most 2^-24 of its own magnitude (which the
+                    // plane distance itself need not share: the node's origin can be far from a plane on the ray's scale), and four times
+                    // that much is added to the allowance of the comparison.  The far constants of an axis are its near ones times
+                    // (1 + w) / (1 - w) (make_box_ray), so the largest near term and the ray's largest such ratio (eps_far) bound them all;
+                    // an axis whose far slot is open has the constants (0, 3e38) and no rounding.
+                    const float sanx = stx * br.anx, sany = sty * br.any, sanz = stz * br.anz, safx = stx * br.afx, safy = sty * br.afy, safz = stz * br.afz;
+                    const float onx = __builtin_fmaf(w0.x, br.anx, br.cnx), ony = __builtin_fmaf(w0.y, br.any, br.cny), onz = __builtin_fmaf(w0.z, br.anz, br.cnz);
+                    const float ofx = __builtin_fmaf(w0.x, br.afx, br.cfx), ofy = __builtin_fmaf(w0.y, br.afy, br.cfy), ofz = __builtin_fmaf(w0.z, br.afz, br.cfz);
+                    float omax;
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(omax) : "v"(onx), "v"(ony), "v"(onz));
+                    const float eps_node = __builtin_fmaf(omax, br.eps_far, br.eps);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float nx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xFFu), sanx, onx), fx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xFFu), safx, ofx);
+                        const float ny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xFFu), sany, ony), fy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xFFu), safy, ofy);
+                        const float nz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xFFu), sanz, onz), fz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xFFu), safz, ofz);
+                        float m, tn, tf;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(nz), "v"(t_min));
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(m));
+                        asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(fz), "v"(nh.best_t));
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(m));
+                        const bool hit = tn <= tf + eps_node && cr[k] != pt::kWideAbsent;
+                        key[k] = ((__float_as_uint(tn) & ~3u) | (uint32_t)k) | (hit ? 0u : 0xFFFFFFFFu); // tn >= t_min > 0: its bits order as it does
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         // plane = origin + q * step exactly (the builder's grid guarantees it), then the slab test of box_test2
@@ -2186,6 +2225,7 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                         const bool hit = tn <= tf + br.eps && cr[k] != pt::kWideAbsent;
                         key[k] = ((__float_as_uint(tn) & ~3u) | (uint32_t)k) | (hit ? 0u : 0xFFFFFFFFu); // tn >= t_min > 0: its bits order as it does
                     }
+#endif
                     if (COUNT) nb += 4;
                     if (br.afx == 0.0f || br.afy == 0.0f || br.afz == 0.0f) { // a steep axis (rare): the bound its open far slot leaves out
                         const SteepBounds sb = make_steep_bounds(r, ray_kappa(sc.cone, r.o));
