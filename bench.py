@@ -211,6 +211,27 @@ def main():
         accum[0].zero_()
         cnt = ctx.render_device(cp, accum[0].data_ptr(), render_stream.cuda_stream, want_stats=True)
 
+    # The same step through the host-buffer entry point (pt_render: device film cleared, rendered, copied to the caller's
+    # buffer), wall time per call: the PCIe-inclusive rate.  Reported beside the headline, never as it.
+    pcie = None
+    if rank == 0 and world == 1 and elapsed / args.steps < 0.5:
+        def host_call(out):
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                t = time.perf_counter()
+                _, hs = ctx.render(W, H, my_spp, depth, seed=args.seed, sample_offset=sample_offset, flags=base_flags, out=out)
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            return best, hs["rays"]
+        pageable = np.zeros((H, W, 3), dtype=np.float32)
+        with api.PinnedFilm(H, W) as film:
+            t_pin, r_pin = host_call(film.array)
+        t_page, _ = host_call(pageable)
+        pcie = {"entry": "pt_render", "film_bytes": int(pageable.nbytes),
+                "pinned_host_buffer": {"ms_per_step": t_pin * 1e3, "Mrays_per_s": r_pin / t_pin / 1e6},
+                "pageable_host_buffer": {"ms_per_step": t_page * 1e3, "Mrays_per_s": r_pin / t_page / 1e6}}
+
     if rank == 0:
         B, P = work_per_ray(args.workload)
         bpr, fpr = bytes_per_ray(B, P), flops_per_ray(B, P)
@@ -254,6 +275,8 @@ def main():
                        "seed": args.seed},
             "roofline": roofline,
         }
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(builder, depth, args.seed, W, H, spp)
             tree = cb.pop("bvh")

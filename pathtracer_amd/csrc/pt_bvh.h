@@ -19,7 +19,7 @@ struct Box {
     float lo[3], hi[3];
 };
 
-// How wide a cone the traversal's slab test gives a ray (make_box_ray in pt_tracer.hip).
+// How wide a cone the traversal's slab test gives a ray (make_box_ray in pt_trace.h).
 //
 // The reference's fp32 hit arithmetic accepts hits outside an object's exact volume.  For a sphere at
 // distance |oc| from the ray origin the discriminant of sphere.h:85-101 carries up to

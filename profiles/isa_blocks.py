@@ -5,7 +5,7 @@ isa_mix.COST) and a few opcodes that tell which part of the source it is (byte c
 divide steps: sphere roots; mul_hi: the Philox rounds; ...).  Used to split a kernel's dynamic instruction count
 between its parts together with the per-part issue tallies of the diagnostic build (make prof).
 
-    python profiles/isa_blocks.py pathtracer_amd/csrc/pt_tracer.gfx950.s '<mangled kernel name>' [first_line last_line]
+    python profiles/isa_blocks.py pathtracer_amd/csrc/pt_kernels_ring.gfx950.s '<mangled kernel name>' [first_line last_line]
 """
 import re
 import sys

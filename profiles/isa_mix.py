@@ -6,7 +6,7 @@ conversion, 64-bit integer, 32-bit integer); everything else (moves, selects, co
 known as the remainder.  This script supplies what the counters cannot: the average issue cost of an instruction of
 the 32-bit-integer class and of the remainder class, weighted by how often each opcode occurs in the kernel's code.
 
-    python profiles/isa_mix.py pathtracer_amd/csrc/pt_tracer.gfx950.s '_Z7k_pathsILb0ELb1ELi512ELb0ELi0EE' out.json
+    python profiles/isa_mix.py pathtracer_amd/csrc/pt_kernels_ring.gfx950.s '_Z7k_pathsILb0ELb1ELi512ELb0ELi0EE' out.json
 """
 import collections
 import json

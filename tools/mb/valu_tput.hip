@@ -67,11 +67,18 @@
 #define A_BFI(R) "v_bfi_b32 " R ", " R ", %8, " R "\n"
 #define A_ALIGNBIT(R) "v_alignbit_b32 " R ", " R ", %8, 8\n"
 #define A_MINU(R) "v_min_u32 " R ", " R ", %8\n"
+#define A_FMAMIX(R) "v_fma_mix_f32 " R ", " R ", %8, " R " op_sel_hi:[1,0,0]\n"
+#define A_FMAMIXHI(R) "v_fma_mix_f32 " R ", " R ", %8, " R " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define A_CVTF16(R) "v_cvt_f32_f16 " R ", " R "\n"
+#define A_LSHL16(R) "v_lshlrev_b32 " R ", 16, " R "\n"
+#define A_LSHR16(R) "v_lshrrev_b32 " R ", 16, " R "\n"
+#define A_MAXF(R) "v_max_f32 " R ", " R ", %8\n"
 BENCH(k_fma, A_FMA) BENCH(k_mulhi, A_MULHI) BENCH(k_mullo, A_MULLO) BENCH(k_xor, A_XOR) BENCH(k_bitop3, A_BITOP3)
 BENCH(k_max3, A_MAX3) BENCH(k_min, A_MIN) BENCH(k_rcp, A_RCP) BENCH(k_sqrt, A_SQRT) BENCH(k_cvt, A_CVT) BENCH(k_lshladd, A_LSHLADD) BENCH(k_addu, A_ADDU) BENCH(k_mini, A_MINI) BENCH(k_maxu, A_MAXU) BENCH(k_min3, A_MIN3) BENCH(k_med3, A_MED3) BENCH(k_mulf, A_MULF) BENCH(k_addf, A_ADDF) BENCH(k_subf, A_SUBF) BENCH(k_and, A_AND) BENCH(k_lshl, A_LSHL) BENCH(k_mov, A_MOV) BENCH(k_cnd, A_CND) BENCH(k_cmp, A_CMP) BENCH(k_fmac, A_FMAC) BENCH(k_max3i, A_MAX3I) BENCH(k_madu24, A_MADU24) BENCH(k_bfe, A_BFE) BENCH(k_add3, A_ADD3)
 BENCH(k_cnd_sgpr, A_CNDS) BENCH(k_divfixup, A_DIVFIX) BENCH(k_divfmas, A_DIVFMAS) BENCH(k_divscale, A_DIVSCALE) BENCH(k_cmpclass, A_CMPCLASS) BENCH(k_not, A_NOT)
 BENCH(k_subu, A_SUBU) BENCH(k_lshr, A_LSHR) BENCH(k_mbcnt, A_MBCNT) BENCH(k_cmpu, A_CMPU) BENCH(k_or, A_OR) BENCH(k_lshlor, A_LSHLOR) BENCH(k_mulu24, A_MULU24)
 BENCH(k_perm, A_PERM) BENCH(k_cvtb0, A_CVTB0) BENCH(k_cvtb3, A_CVTB3) BENCH(k_andor, A_ANDOR) BENCH(k_bfi, A_BFI) BENCH(k_alignbit, A_ALIGNBIT) BENCH(k_minu, A_MINU)
+BENCH(k_fmamix, A_FMAMIX) BENCH(k_fmamixhi, A_FMAMIXHI) BENCH(k_cvtf16, A_CVTF16) BENCH(k_lshl16, A_LSHL16) BENCH(k_lshr16, A_LSHR16) BENCH(k_maxf, A_MAXF)
 typedef float f2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(1024) void k_pkfma(uint32_t *out, uint32_t seed)
 {
@@ -116,5 +123,6 @@ int main()
         printf("%-10s %.3f ms  %.2f cycles per wave-instruction per SIMD\n", #K, ms, ms * 1e-3 * ghz * 1e9 / inst_per_simd); \
     }
     RUN(k_fma) RUN(k_fma) RUN(k_min) RUN(k_fma) RUN(k_mini) RUN(k_maxu) RUN(k_min3) RUN(k_med3) RUN(k_max3i) RUN(k_mulf) RUN(k_addf) RUN(k_subf) RUN(k_fmac) RUN(k_and) RUN(k_lshl) RUN(k_mov) RUN(k_cnd) RUN(k_cmp) RUN(k_madu24) RUN(k_bfe) RUN(k_add3) RUN(k_addu) RUN(k_xor) RUN(k_bitop3) RUN(k_min) RUN(k_max3) RUN(k_lshladd) RUN(k_cvt) RUN(k_mulhi) RUN(k_mullo) RUN(k_mad64) RUN(k_pkfma) RUN(k_rcp) RUN(k_sqrt) RUN(k_cnd_sgpr) RUN(k_divfixup) RUN(k_divfmas) RUN(k_divscale) RUN(k_cmpclass) RUN(k_not) RUN(k_subu) RUN(k_lshr) RUN(k_mbcnt) RUN(k_cmpu) RUN(k_or) RUN(k_lshlor) RUN(k_mulu24) RUN(k_perm) RUN(k_cvtb0) RUN(k_cvtb3) RUN(k_andor) RUN(k_bfi) RUN(k_alignbit) RUN(k_minu)
+    RUN(k_fmamix) RUN(k_fmamixhi) RUN(k_cvtf16) RUN(k_lshl16) RUN(k_lshr16) RUN(k_maxf) RUN(k_fma)
     return 0;
 }
