@@ -128,7 +128,7 @@ typedef struct pt_tuning {
     int32_t leaf_max;          /* objects per tree leaf, 1..8; applies from the next pt_scene_upload */
     int32_t wide_nodes;        /* 0 / 1: four-wide quantised nodes for scenes traversed from HBM; next pt_scene_upload */
     int32_t pipeline;          /* 0 queue-based persistent workgroups, a slice at a time (k_paths); 1 streaming lanes (k_paths_stream); 2 queue-based with the
-                                  slices of a workgroup overlapped (k_paths_ring; scenes that fit on-chip memory, max_depth <= 2047) */
+                                  slices of a workgroup overlapped (k_paths_ring; scenes that fit on-chip memory, max_depth <= 1023) */
     int32_t lds_scene;         /* 0: never copy the scene into LDS */
     int32_t block;             /* threads per workgroup: 256 or 512 */
     int32_t workgroups_per_cu; /* 1..16 */

@@ -813,7 +813,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     // workgroup to balance (a slice's cost varies several-fold with what its pixels see).
     const uint64_t total_paths = (uint64_t)n_pixels * pr->spp;
     bool ring = sh.ring && pr->max_depth <= PT_RING_MAX_DEPTH;
-    uint32_t spass = 0, pix = 0, cap = 0;
+    uint32_t spass = 0, pix = 0, cap = 0, ring_pix_bits = 0;
     for (;;) {
         // k_paths_ring keeps its queue filled across slices, so its slices only have to be small enough to balance the end
         // of the frame (16 per resident workgroup) and large enough to be worth a ticket
@@ -825,7 +825,13 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         pix = std::max(64u, (target / spass) & ~63u);
         if ((uint64_t)pix * spass * 3 >= (1ull << 32)) return fail(ctx, PT_ERR_LIMIT, "samples_per_pass too large for one slice");
         cap = pix * spass;
-        if (ring && cap > (1u << PT_RING_LID_BITS)) { ring = false; continue; } // a slice too large for the ring's path index: k_paths
+        if (ring) { // a slice too large for the ring's path word (pixel and sample side by side in PT_RING_PATH_BITS bits): k_paths
+            ring_pix_bits = 6;
+            while ((1u << ring_pix_bits) < pix) ++ring_pix_bits;
+            uint32_t sample_bits = 0;
+            while ((1u << sample_bits) < spass) ++sample_bits;
+            if (ring_pix_bits + sample_bits > PT_RING_PATH_BITS || cap > 65536u) { ring = false; continue; } // (and PT_RING radiance buffers of that size per workgroup)
+        }
         break;
     }
     PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -916,7 +922,7 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
         if (ring) {
             RingDev rg;
             rg.qA = ctx->d_gA; rg.qB = ctx->d_gB; rg.qC = ctx->d_gC; rg.rad = ctx->d_grad;
-            rg.qcap = qcap; rg.cap = cap; rg.low_water = low_water; rg.n_slices = n_slices; rg.extents = ctx->d_extents; rg.ticket = ctx->d_ticket;
+            rg.qcap = qcap; rg.cap = cap; rg.low_water = low_water; rg.pix_bits = ring_pix_bits; rg.n_slices = n_slices; rg.extents = ctx->d_extents; rg.ticket = ctx->d_ticket;
             pt_launch_ring(count, ctx->kind, ctx->d_cnt, scene, stream, block, split, grid, lds_bytes, ps, rg, d_rgb_sum);
         } else {
             pt_launch_paths(count, ctx->kind, ctx->d_cnt, scene, stream, block, lds, sort, split, grid, lds_bytes, ps, sl, d_rgb_sum);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long rays = 0;
     uint32_t nb = 0, np = 0, nf = 0, nr = 0;
-    uint32_t extra_rays = 0; // rays traced from a lane without passing through a queue (the end of the launch)
+    uint32_t my_rays = 0; // rays this lane traced
     ProfLanes prof;
     unsigned long long sect[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long t_last = kProf ? clock64() : 0;
@@ -89,8 +89,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
         s_open = 0; s_exhausted = 0; s_fresh_n = 0; s_fresh_slot = 0; s_chunk = 0;
         take_ahead();
     }
-    constexpr uint32_t LID_MASK = (1u << PT_RING_LID_BITS) - 1u, SLOT_MASK = (1u << PT_RING_SLOT_BITS) - 1u, ALL_OPEN = (1u << PT_RING) - 1u;
-    constexpr uint32_t BOUNCE_ONE = 1u << (PT_RING_LID_BITS + PT_RING_SLOT_BITS);
+    constexpr uint32_t PATH_MASK = (1u << PT_RING_PATH_BITS) - 1u, SLOT_MASK = (1u << PT_RING_SLOT_BITS) - 1u, ALL_OPEN = (1u << PT_RING) - 1u;
+    constexpr uint32_t BOUNCE_ONE = 1u << (PT_RING_PATH_BITS + PT_RING_SLOT_BITS);
+    const uint32_t pix_bits = rg.pix_bits, pix_mask = (1u << pix_bits) - 1u;
     uint32_t cur = 0;
     uint32_t summed = 0; // slices summed into the film during the last generation: their slots are free from this one on
     long long t_drain = 0;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
             r.o = V(0.0f, 0.0f, 0.0f);
             r.d = V(0.0f, 0.0f, 0.0f);
             v3 T = V(1.0f, 1.0f, 1.0f);
-            uint32_t idw = 0; // path index within its slice | ring slot | bounces so far
+            uint32_t idw = 0; // the path word: pixel within its slice | sample within the pass | ring slot | bounces so far
             HitResult h;
             h.t = 0.0f;
             h.slot = PT_NO_PRIM;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
                     // the new slice's camera rays, numbered sample-fast: a wave starts with the samples of one or a few pixels
                     const uint32_t f = i - n_queue;
                     const uint32_t pl = f / ps.samples, s = f - pl * ps.samples;
-                    idw = (s * fresh_npix + pl) | (fresh_slot << PT_RING_LID_BITS);
+                    idw = pl | (s << pix_bits) | (fresh_slot << PT_RING_PATH_BITS);
                     r = camera_ray(sc.cam, ps, fresh_pix0 + pl, ps.sample_base + s);
                 }
             }
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
             for (;;) { // (once, except at the end of the launch)
             h.slot = PT_NO_PRIM;
             if (valid_now) {
+                my_rays++;
                 bool need_exact;
                 const int32_t root_ref = FLAT ? sc.root_ref : 0;
                 if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK, LdsSrc, FLAT>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
@@ -199,7 +201,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
             // main.cu:54-64 for the traced ray, then compaction of the wave's survivors into the next queue
             survive = false;
             if (valid_now) {
-                const uint32_t lid = idw & LID_MASK, slot = (idw >> PT_RING_LID_BITS) & SLOT_MASK;
+                // pixel within the slice and sample within the pass, as the path word holds them: no division by the slice's width
+                const uint32_t pl = idw & pix_mask, s = (idw & PATH_MASK) >> pix_bits, slot = (idw >> PT_RING_PATH_BITS) & SLOT_MASK;
+                const uint32_t lid = s * s_npix[slot] + pl; // where the path reports in its slice's radiance buffer
                 v3 result;
                 if (h.slot == PT_NO_PRIM) {
                     result = vmul(T, V(sc.bg[0], sc.bg[1], sc.bg[2])); // main.cu:54-55
@@ -214,12 +218,10 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
                     } else {
                         q = load_prim((h.slot & 0x80000000u) ? sc.prims_list : sc.prims, h.slot & 0x7FFFFFFFu);
                     }
-                    const uint32_t npix = s_npix[slot];
-                    const uint32_t s = lid / npix, pl = lid - s * npix;
                     Ray nray;
                     v3 nT;
                     if (kProf) prof.tick(3);
-                    survive = shade_hit<KIND == PT_KIND_SPHERES>(sc.mats, ps, r, T, s_pix0[slot] + pl, ps.sample_base + s, (int32_t)(idw >> (PT_RING_LID_BITS + PT_RING_SLOT_BITS)), q, h.t,
+                    survive = shade_hit<KIND == PT_KIND_SPHERES>(sc.mats, ps, r, T, s_pix0[slot] + pl, ps.sample_base + s, (int32_t)(idw >> (PT_RING_PATH_BITS + PT_RING_SLOT_BITS)), q, h.t,
                                                                  nray, nT, result, &prof);
                     if (survive) {
                         oA = make_float4(nray.o.x, nray.o.y, nray.o.z, __uint_as_float(idw + BOUNCE_ONE));
@@ -243,7 +245,6 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
                 r.d = V(oB.x, oB.y, oB.z);
                 T = V(oB.w, oC.x, oC.y);
                 idw = __float_as_uint(oA.w);
-                extra_rays++;
             }
             }
             if (SPLIT) { // as in k_paths: rays that head up (camera's up vector) from the back of the next queue, the others from its front
@@ -292,7 +293,6 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
             if (threadIdx.x == 0) { sect[7] += 1; prof.lanes[5] += total; }
         }
         if (last) break; // (every slice still open had no path left: summed just now or a generation ago)
-        if (threadIdx.x == 0) rays += total;
         summed = closing;
         cur ^= 1u;
     }
@@ -305,10 +305,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
         if (lane == 0)
             for (int k = 0; k < 8; ++k) atomicAdd(&cnt->sect[k], sect[k]);
     }
-    {
-        const unsigned long long ex = wave_sum_u32(extra_rays);
-        if (lane == 0) rays += ex;
-    }
+    rays = wave_sum_u32(my_rays);
     if (lane == 0 && rays) atomicAdd(&cnt->rays, rays);
     if (COUNT) {
         unsigned long long sb = wave_sum_u32(nb), sp = wave_sum_u32(np);

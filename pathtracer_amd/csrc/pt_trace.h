@@ -1070,9 +1070,9 @@ struct SliceDev {
 
 // k_paths_ring (pt_kernels_ring.hip)
 #define PT_RING 16           // slices a workgroup may have under way
-#define PT_RING_LID_BITS 17  // a path's index within its slice (sample * pixels + pixel)
+#define PT_RING_PATH_BITS 18 // a path within its slice: pixel (the low RingDev::pix_bits bits) and sample of the pass (the bits above)
 #define PT_RING_SLOT_BITS 4
-#define PT_RING_MAX_DEPTH ((1 << (32 - PT_RING_LID_BITS - PT_RING_SLOT_BITS)) - 1) // the bounce count has the word's other 11 bits
+#define PT_RING_MAX_DEPTH ((1 << (32 - PT_RING_PATH_BITS - PT_RING_SLOT_BITS)) - 1) // the bounce count has the word's other 10 bits
 struct RingDev {
     float4 *qA;   // [grid][2][qcap]
     float4 *qB;
@@ -1081,6 +1081,7 @@ struct RingDev {
     uint32_t qcap;      // entries per queue: low_water + cap
     uint32_t cap;       // paths of the largest slice
     uint32_t low_water; // a generation that starts with fewer queued rays than this takes the next slice as well
+    uint32_t pix_bits;  // bits of a path word that hold the pixel within the slice (every slice has at most 2^pix_bits pixels)
     uint32_t n_slices;
     const uint2 *extents; // [n_slices] (first pixel, pixels)
     uint32_t *ticket;

@@ -82,6 +82,14 @@ def test_pipelines_agree_bitwise(ctx, name, w, h, spp, depth):
         img, s2 = ctx.render(w, h, spp, depth, **kw)
         assert s2["rays"] == st["rays"], tag
         assert np.array_equal(img.view(np.uint32), base.view(np.uint32)), tag
+    counts = []
+    for pipe in (0, 1, 2):  # the counting variants of the three persistent kernels do the same work per ray on a scene in LDS ...
+        with ctx.tuned(pipeline=pipe, leaf_max=4, wide_nodes=0):
+            _, sc = ctx.render(w, h, spp, depth, flags=api.RENDER_COUNT_TESTS | (api.RENDER_NO_LDS_SCENE if pipe == 1 else 0))
+        assert sc["rays"] == st["rays"] and sc["box_tests"] > st["rays"], pipe
+        counts.append((sc["kernel"], sc["box_tests"], sc["prim_tests"]))
+    if counts[2][0] == 4:  # (k_paths_stream steps differently, and it is what renders a scene too large for LDS)
+        assert counts[0][1:] == counts[2][1:], counts
     for tune in (dict(block=256), dict(sort_by_material=1), dict(slice_paths=4096), dict(slice_paths=1000000),
                  dict(split_queue=0), dict(split_queue=1),  # survivors in one queue / rays that head up queued apart
                  # scene in HBM: the streaming kernel (default there) at several batching thresholds and
