@@ -96,11 +96,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1984)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="the timed region and the roofline only: no CPU baseline, no PCIe-inclusive and no two-in-flight figures (profiling runs)")
     ap.add_argument("--scaling", default=os.environ.get("PT_BENCH_SCALING", "strong"), choices=["weak", "strong"],
                     help="strong (default): the workload's spp is cut into N ranges, the image is the named configuration's; weak: every GPU renders the workload's spp (the image gets N x spp)")
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
     ap.add_argument("--force-collective", action="store_true", help="with one GPU: still create the process group (one rank) and run the all-reduce on its stream, to rehearse the N > 1 code path")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                    help="2: consecutive steps alternate between two contexts (each with its own workspace) on two streams, so the tail of one step's "
+                         "persistent kernel overlaps the start of the next (not the headline configuration: launch times then overlap and exceed ms_per_step)")
     ap.add_argument("--cull", default="cone", choices=["cone", "geometric"], help="geometric: PT_RENDER_GEOMETRIC_CULL (labelled in the output; not the headline configuration)")
     args = ap.parse_args()
 
@@ -136,6 +139,10 @@ def main():
     builder = wl["scene"]()
     ctx = api.Context(local_rank)
     ctx.upload(builder.desc())
+    ctxs = [ctx]
+    for _ in range(args.in_flight - 1):
+        ctxs.append(api.Context(local_rank))
+        ctxs[-1].upload(builder.desc())
     W, H, spp, depth = wl["w"], wl["h"], wl["spp"], wl["depth"]
     name = wl["name"]
     if args.spp > 0:
@@ -149,6 +156,7 @@ def main():
     # two accumulation buffers: the all-reduce of one step runs on its own stream while the next step renders
     accum = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     render_stream = torch.cuda.current_stream()
+    render_streams = [render_stream] + [torch.cuda.Stream() for _ in range(args.in_flight - 1)]
     # high priority: when a render ends, the all-reduce of its buffer and the next render both become ready, and the
     # reduction's few workgroups should get their slots before the persistent render kernel takes every CU
     comm_stream = torch.cuda.Stream(priority=-1) if dist is not None else None
@@ -158,17 +166,20 @@ def main():
 
     def step(k, want_stats=False, flags=0, ev=None):
         buf = accum[k & 1]
-        if reduced[k & 1] is not None:
-            render_stream.wait_event(reduced[k & 1])  # the buffer's previous all-reduce has finished
-        buf.zero_()
-        params.flags = base_flags | flags
-        if ev is not None:
-            ev[0].record(render_stream)
-        st = ctx.render_device(params, buf.data_ptr(), render_stream.cuda_stream, want_stats=want_stats)
-        if ev is not None:
-            ev[1].record(render_stream)
+        rs = render_streams[k % len(render_streams)]
+        cx = ctxs[k % len(ctxs)]
+        with torch.cuda.stream(rs):
+            if reduced[k & 1] is not None:
+                rs.wait_event(reduced[k & 1])  # the buffer's previous all-reduce has finished
+            buf.zero_()
+            params.flags = base_flags | flags
+            if ev is not None:
+                ev[0].record(rs)
+            st = cx.render_device(params, buf.data_ptr(), rs.cuda_stream, want_stats=want_stats)
+            if ev is not None:
+                ev[1].record(rs)
         if comm_stream is not None:  # linear sums; gamma comes after (main.cu:95-98 is non-linear)
-            rendered[k & 1].record(render_stream)
+            rendered[k & 1].record(rs)
             comm_stream.wait_event(rendered[k & 1])
             with torch.cuda.stream(comm_stream):
                 distributed.all_reduce_sum(buf)
@@ -211,10 +222,33 @@ def main():
         accum[0].zero_()
         cnt = ctx.render_device(cp, accum[0].data_ptr(), render_stream.cuda_stream, want_stats=True)
 
+    # The same K steps with two of them in flight: consecutive steps alternate between two contexts (each with its own
+    # workspace) on two streams, so that the last rays of one step's persistent kernel -- a handful of paths fifty bounces
+    # deep, most of the GPU idle -- overlap the start of the next.  What a caller that renders frame after frame gets;
+    # reported beside the headline, never as it (the launches then overlap, and a launch's own duration exceeds the step's).
+    pipelined = None
+    if world == 1 and args.in_flight == 1 and not args.no_cpu_baseline and elapsed / args.steps < 0.5:
+        ctxs.append(api.Context(local_rank))
+        ctxs[-1].upload(builder.desc())
+        render_streams.append(torch.cuda.Stream())
+        for k in range(4):
+            step(k)
+        sync()
+        t0p = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        sync()
+        dtp = time.perf_counter() - t0p
+        pipelined = {"steps_in_flight": 2, "ms_per_step": dtp / args.steps * 1e3, "Mrays_per_s": rays_step * args.steps / dtp / 1e6,
+                     "note": "two contexts on two streams, steps alternating; same work per step"}
+        ctxs.pop().close()
+        render_streams.pop()
+        torch.cuda.synchronize()
+
     # The same step through the host-buffer entry point (pt_render: device film cleared, rendered, copied to the caller's
     # buffer), wall time per call: the PCIe-inclusive rate.  Reported beside the headline, never as it.
     pcie = None
-    if rank == 0 and world == 1 and elapsed / args.steps < 0.5:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and elapsed / args.steps < 0.5:
         def host_call(out):
             torch.cuda.synchronize()
             best = None
@@ -269,7 +303,7 @@ def main():
             "metric": "Mrays/s (incl. secondary bounces)", "value": rays_step * args.steps / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "width": W, "height": H, "spp_per_gpu": my_spp, "spp_total": spp_total,
+            "config": {"workload": name + (" [%d steps in flight]" % args.in_flight if args.in_flight > 1 else ""), "width": W, "height": H, "spp_per_gpu": my_spp, "spp_total": spp_total,
                        "max_depth": depth, "objects": int(len(builder.arrays()["prim_type"])), "rays_per_step": rays_step,
                        "parallelism": "spp-sharded x%d (%s) + all-reduce(sum) of the fp32 accumulation buffer, overlapped with the next step's render" % (world, args.scaling),
                        "seed": args.seed},
@@ -277,6 +311,8 @@ def main():
         }
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(builder, depth, args.seed, W, H, spp)
             tree = cb.pop("bvh")
@@ -284,7 +320,8 @@ def main():
             out["cpu_baseline"] = cb
             out["cpu_baseline_tree"] = tree
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ root, out, desc, key = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 isa = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else None
 here = os.path.dirname(os.path.abspath(__file__))
 summ = json.load(open(os.path.join(root, "summary.json")))
-kern = next((k for k in summ["kernels"] if k.startswith("k_paths_stream<false")), None) or next(k for k in summ["kernels"] if k.startswith("k_paths<false"))
+kern = next((k for k in summ["kernels"] if k.startswith("k_paths_stream<false")), None) or next((k for k in summ["kernels"] if k.startswith("k_paths_ring<false")), None) or next(k for k in summ["kernels"] if k.startswith("k_paths<false"))
 c = {n: v["per_launch"] for n, v in summ["kernels"][kern].items()}
 bench = None
 for line in open(os.path.join(root, "sq.log")):

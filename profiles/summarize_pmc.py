@@ -18,7 +18,7 @@ out = {}
 for k in sorted(agg):
     out[k] = {c: {"sum": v, "launches": len(launches[k][c]), "per_launch": v / max(1, len(launches[k][c]))} for c, v in sorted(agg[k].items())}
 summary = {"workload": workload, "kernels": out}
-ki = next((k for k in out if k.startswith("k_paths_stream<false")), None) or next((k for k in out if k.startswith("k_paths<false")), None) or next((k for k in out if k.startswith("k_intersect<false")), None)
+ki = next((k for k in out if k.startswith("k_paths_stream<false")), None) or next((k for k in out if k.startswith("k_paths_ring<false")), None) or next((k for k in out if k.startswith("k_paths<false")), None) or next((k for k in out if k.startswith("k_intersect<false")), None)
 res = {}
 if ki and "FETCH_SIZE" in out[ki] and "WRITE_SIZE" in out[ki]:
     fetch = out[ki]["FETCH_SIZE"]["per_launch"] * 1024.0
