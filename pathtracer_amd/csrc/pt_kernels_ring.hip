@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
         __syncthreads(); // (C) thread 0's decisions are visible
         mark(0);
         const uint32_t fresh_n = s_fresh_n, fresh_slot = s_fresh_slot;
-        const uint32_t fresh_pix0 = s_pix0[fresh_slot], fresh_npix = s_npix[fresh_slot];
+        const uint32_t fresh_pix0 = s_pix0[fresh_slot];
         const uint32_t total = n_queue + fresh_n;
         const bool last = total == 0 && s_exhausted != 0; // nothing queued, nothing left to take
         // The end of the launch: no slice left to take and at most one chunk per wave queued.  Every wave then keeps the
