@@ -637,9 +637,11 @@ static PathsShape paths_shape(pt_context *ctx, uint32_t flags, bool count, bool 
         // SIMD instead of the 3 its 132 registers at 256 allow: 100k mixed objects 2.40 -> 2.85 Grays/s)
         const bool fits_lds = want_lds && !force_stream && scene_bytes + (size_t)sc.stack_cap * 512 * 4 <= 64 * 1024;
         block = fits_lds || ctx->has_cones ? 512 : 256;
-        // A scene so small that six workgroups of 256 share a CU's LDS: the smaller workgroups balance a large frame
-        // better (Cornell box at 1024 x 1024 x 1024 spp: 250.7 -> 241.6 ms; a frame of 1.4 M paths loses 5 %).
-        if (fits_lds && 6 * (scene_bytes + (size_t)sc.stack_cap * 256 * 4 + 64) <= 160 * 1024 && total_paths >= (16ull << 20)) block = 256;
+        // k_paths on a scene so small that six workgroups of 256 share a CU's LDS: the smaller workgroups balance a large
+        // frame better (Cornell box at 1024 x 1024 x 1024 spp: 250.7 -> 241.6 ms; a frame of 1.4 M paths loses 5 %).  Not
+        // k_paths_ring, whose chunks go to whichever wave is free: the Cornell box at 256 spp 41.8 ms with 256, 39.1 with 512.
+        const bool one_slice_at_a_time = ps.sort || tuned(tu.pipeline, PT_DEFAULT_LDS_PIPELINE) == 0;
+        if (fits_lds && one_slice_at_a_time && 6 * (scene_bytes + (size_t)sc.stack_cap * 256 * 4 + 64) <= 160 * 1024 && total_paths >= (16ull << 20)) block = 256;
     }
     ps.block = block;
     const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
@@ -817,7 +819,8 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     for (;;) {
         // k_paths_ring keeps its queue filled across slices, so its slices only have to be small enough to balance the end
         // of the frame (16 per resident workgroup) and large enough to be worth a ticket
-        const uint32_t balanced = ring ? (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(2048, total_paths / (16ull * grid_max)))
+        // (random spheres at 64 spp: 12.4 ms with slices of 4096 paths, 12.65 with 8192; the Cornell box at 256 spp 38.9 against 39.2)
+        const uint32_t balanced = ring ? (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(2048, total_paths / (16ull * grid_max)))
                                        : (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(4096, total_paths / (4ull * grid_max)));
         const uint32_t target = (uint32_t)tuned(ctx->tune.slice_paths, (int)balanced);
         spass = pr->samples_per_pass ? pr->samples_per_pass : std::max(1u, target / 64u);
@@ -865,9 +868,10 @@ static pt_status render_slices(pt_context *ctx, const pt_render_params *pr, floa
     const uint32_t grid = std::min(grid_max, n_slices);
 
     // k_paths_ring: a new slice joins a queue of fewer than low_water rays
-    // (four chunks per wave: random spheres 13.6 ms at 1024 .. 4096 against 13.9 at 512 and 14.5 at 16384, where every generation
-    // takes a slice; the Cornell box is flat from 256 to 1024)
-    const uint32_t low_water = std::max(1u, (uint32_t)tuned(ctx->tune.ring_low_water, 4 * block));
+    // (two chunks per wave: random spheres 13.6 ms at 1024 .. 4096 against 13.9 at 512 and 14.5 at 16384, where every generation
+    // takes a slice)
+    // Cornell box at 256 spp (512 threads): 38.9 ms at 1024, 39.1 at 2048, 42.5 at 4096.
+    const uint32_t low_water = std::max(1u, (uint32_t)tuned(ctx->tune.ring_low_water, 2 * block));
     const uint32_t qcap = low_water + cap;
     if (ring) {
         const size_t need_q = (size_t)grid * 2 * qcap, need_r = (size_t)grid * PT_RING * cap;
