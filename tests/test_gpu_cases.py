@@ -176,6 +176,19 @@ def test_scene_of_one_leaf(ctx):
         assert s2["rays"] == rays and np.array_equal(img.view(np.uint32), base.view(np.uint32)), flags
 
 
+def test_depth_beyond_the_ring_kernels_bounce_counter(ctx):
+    """k_paths_ring keeps a path's bounce count in 10 bits of its id word; a render with max_depth above 1023 is k_paths'.
+    In the closed Cornell box paths do run long (a render at depth 1023 traces more rays than one at depth 20), but none
+    reaches a thousand bounces: depth 1023 (k_paths_ring) and depth 2000 (k_paths) give the same image, bit for bit."""
+    ctx.upload(scenes.cornell_scene().desc())
+    a, sa = ctx.render(48, 48, 8, 1023)
+    b, sb = ctx.render(48, 48, 8, 2000)
+    c, sc = ctx.render(48, 48, 8, 20)
+    assert (sa["kernel"], sb["kernel"], sc["kernel"]) == (4, 1, 4)
+    assert sa["rays"] == sb["rays"] > sc["rays"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_render_is_deterministic_and_seeded(ctx):
     ctx.upload(scenes.random_spheres_scene().desc())
     a, _ = ctx.render(160, 90, 3, 50)
