@@ -117,6 +117,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # stdout carries the one JSON line and nothing else: what libraries print there while the run lasts (RCCL's version
+    # banner at the first collective) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or args.force_collective:
         import torch.distributed as dist
@@ -319,7 +324,7 @@ def main():
             cb["sample"] += "; the same walk through a CPU-built tree (not the reference's algorithm): %.1f Mrays/s on %d cores" % (tree["value"], tree["cores"])
             out["cpu_baseline"] = cb
             out["cpu_baseline_tree"] = tree
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for cx in ctxs:
         cx.close()
     if dist is not None:
