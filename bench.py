@@ -89,6 +89,9 @@ def cpu_baseline(scene_builder, depth, seed, W, H, SPP):
     return out
 
 
+IN_FLIGHT_BELOW_MS = 8.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,9 +104,11 @@ def main():
                     help="strong (default): the workload's spp is cut into N ranges, the image is the named configuration's; weak: every GPU renders the workload's spp (the image gets N x spp)")
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (profiling runs; not the headline configuration)")
     ap.add_argument("--force-collective", action="store_true", help="with one GPU: still create the process group (one rank) and run the all-reduce on its stream, to rehearse the N > 1 code path")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
-                    help="2: consecutive steps alternate between two contexts (each with its own workspace) on two streams, so the tail of one step's "
-                         "persistent kernel overlaps the start of the next (not the headline configuration: launch times then overlap and exceed ms_per_step)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="steps in flight.  2: consecutive steps alternate between two contexts (each with its own workspace) on two streams, "
+                         "so the last bounces of one step's persistent kernel (a few waves, most of the GPU idle) overlap the start of the next.  "
+                         "0 (default): 2 when a step alone takes less than %g ms, where that tail is a large part of the step (C2 at 8 / 16 / 32 spp: "
+                         "2.15 -> 1.76, 3.66 -> 3.35, 6.60 -> 6.16 ms per step), else 1 (C2 at 48 / 64 spp: 9.48 -> 9.78, 12.37 -> 12.80 ms)" % IN_FLIGHT_BELOW_MS)
     ap.add_argument("--cull", default="cone", choices=["cone", "geometric"], help="geometric: PT_RENDER_GEOMETRIC_CULL (labelled in the output; not the headline configuration)")
     args = ap.parse_args()
 
@@ -145,9 +150,6 @@ def main():
     ctx = api.Context(local_rank)
     ctx.upload(builder.desc())
     ctxs = [ctx]
-    for _ in range(args.in_flight - 1):
-        ctxs.append(api.Context(local_rank))
-        ctxs[-1].upload(builder.desc())
     W, H, spp, depth = wl["w"], wl["h"], wl["spp"], wl["depth"]
     name = wl["name"]
     if args.spp > 0:
@@ -161,7 +163,7 @@ def main():
     # two accumulation buffers: the all-reduce of one step runs on its own stream while the next step renders
     accum = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     render_stream = torch.cuda.current_stream()
-    render_streams = [render_stream] + [torch.cuda.Stream() for _ in range(args.in_flight - 1)]
+    render_streams = [render_stream]
     # high priority: when a render ends, the all-reduce of its buffer and the next render both become ready, and the
     # reduction's few workgroups should get their slots before the persistent render kernel takes every CU
     comm_stream = torch.cuda.Stream(priority=-1) if dist is not None else None
@@ -197,9 +199,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    st0 = step(0, want_stats=True)  # ray count of this rank's sample range (deterministic per step)
-    for k in range(max(0, args.warmup - 1)):
-        step(k + 1)
+    # Set-up, untimed: the ray count of this rank's sample range (deterministic per step), then one step alone to decide
+    # how many steps to keep in flight (the slowest rank's time decides for all), then the second context's first step
+    # (its workspace is allocated there).
+    st0 = step(0, want_stats=True)
+    sync()
+    t_alone = time.perf_counter()
+    step(1)
+    sync()
+    alone_t = torch.tensor([time.perf_counter() - t_alone], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(alone_t, op=dist.ReduceOp.MAX)
+    ms_alone = alone_t.item() * 1e3
+    in_flight = args.in_flight if args.in_flight > 0 else (2 if ms_alone < IN_FLIGHT_BELOW_MS else 1)
+    if in_flight == 2:
+        ctxs.append(api.Context(local_rank))
+        ctxs[-1].upload(builder.desc())
+        render_streams.append(torch.cuda.Stream())
+        step(1)
+        sync()
+    for k in range(args.warmup):
+        step(k)
     sync()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -232,23 +252,39 @@ def main():
     # deep, most of the GPU idle -- overlap the start of the next.  What a caller that renders frame after frame gets;
     # reported beside the headline, never as it (the launches then overlap, and a launch's own duration exceeds the step's).
     pipelined = None
-    if world == 1 and args.in_flight == 1 and not args.no_cpu_baseline and elapsed / args.steps < 0.5:
+    if world == 1 and in_flight == 1 and not args.no_cpu_baseline and elapsed / args.steps < 0.5:
         ctxs.append(api.Context(local_rank))
         ctxs[-1].upload(builder.desc())
         render_streams.append(torch.cuda.Stream())
         for k in range(4):
             step(k)
         sync()
+        n_extra = max(args.steps, 40)  # the two streams settle into their steady state after some ten steps
+        t0p = time.perf_counter()
+        for k in range(n_extra):
+            step(k)
+        sync()
+        dtp = time.perf_counter() - t0p
+        pipelined = {"steps_in_flight": 2, "steps": n_extra, "ms_per_step": dtp / n_extra * 1e3, "Mrays_per_s": rays_step * n_extra / dtp / 1e6,
+                     "note": "two contexts on two streams, steps alternating; same work per step"}
+        ctxs.pop().close()
+        render_streams.pop()
+        torch.cuda.synchronize()
+    # ... and, when the headline keeps two in flight, the same K steps one at a time
+    unpipelined = None
+    if world == 1 and in_flight == 2 and not args.no_cpu_baseline:
+        sync()
+        spare_ctx, spare_stream = ctxs.pop(), render_streams.pop()
+        step(0)
+        sync()
         t0p = time.perf_counter()
         for k in range(args.steps):
             step(k)
         sync()
         dtp = time.perf_counter() - t0p
-        pipelined = {"steps_in_flight": 2, "ms_per_step": dtp / args.steps * 1e3, "Mrays_per_s": rays_step * args.steps / dtp / 1e6,
-                     "note": "two contexts on two streams, steps alternating; same work per step"}
-        ctxs.pop().close()
-        render_streams.pop()
-        torch.cuda.synchronize()
+        unpipelined = {"steps_in_flight": 1, "ms_per_step": dtp / args.steps * 1e3, "Mrays_per_s": rays_step * args.steps / dtp / 1e6}
+        ctxs.append(spare_ctx)
+        render_streams.append(spare_stream)
 
     # The same step through the host-buffer entry point (pt_render: device film cleared, rendered, copied to the caller's
     # buffer), wall time per call: the PCIe-inclusive rate.  Reported beside the headline, never as it.
@@ -276,7 +312,10 @@ def main():
         bpr, fpr = bytes_per_ray(B, P), flops_per_ray(B, P)
         n_launch = max(1, prof["launches_intersect"])
         kernel = api.KERNEL_NAMES.get(prof["kernel"], "?")
-        ms_launch = ms_render / n_launch
+        # with two steps in flight a launch's start event is recorded while the previous step still holds the GPU, so the
+        # events of the timed region measure queueing too: the launch duration is then the library's own, from the step
+        # that ran alone after the timed region
+        ms_launch = (ms_render if in_flight == 1 else prof["ms_paths"]) / n_launch
         rays_launch = st0["rays"] / n_launch
         tflops = fpr * rays_launch / (ms_launch * 1e-3) / 1e12 if ms_launch > 0 else 0.0
         gbs = bpr * rays_launch / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
@@ -292,6 +331,7 @@ def main():
             "flops_per_ray": fpr, "bytes_per_ray": bpr, "B": B, "P": P, "work_per_ray_source": "profiles/work_per_ray.json",
             "rays_per_launch": rays_launch, "ms_per_launch": ms_launch, "launches": n_launch,
             "ms_per_launch_library_events": prof["ms_paths"] / n_launch,
+            "ms_per_launch_source": "events around the render on its stream, timed region" if in_flight == 1 else "library events of one step alone (launches of the timed region overlap)",
             "hbm": {"algorithmic_GBs": gbs, "peak_GBs": HBM_PEAK_GBS,
                     "measured_GBs": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9) if traffic is not None else None,
                     "measured_frac": (traffic * rays_launch / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic is not None else None},
@@ -308,7 +348,7 @@ def main():
             "metric": "Mrays/s (incl. secondary bounces)", "value": rays_step * args.steps / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name + (" [%d steps in flight]" % args.in_flight if args.in_flight > 1 else ""), "width": W, "height": H, "spp_per_gpu": my_spp, "spp_total": spp_total,
+            "config": {"workload": name + (" [%d steps in flight]" % in_flight if in_flight > 1 else ""), "steps_in_flight": in_flight, "ms_step_alone": ms_alone, "width": W, "height": H, "spp_per_gpu": my_spp, "spp_total": spp_total,
                        "max_depth": depth, "objects": int(len(builder.arrays()["prim_type"])), "rays_per_step": rays_step,
                        "parallelism": "spp-sharded x%d (%s) + all-reduce(sum) of the fp32 accumulation buffer, overlapped with the next step's render" % (world, args.scaling),
                        "seed": args.seed},
@@ -318,6 +358,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if unpipelined is not None:
+            out["unpipelined"] = unpipelined
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(builder, depth, args.seed, W, H, spp)
             tree = cb.pop("bvh")

@@ -12,7 +12,11 @@ run() {
   tail -1 "$OUT" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', 'ms/step %.3f' % d['ms_per_step'], 'Mrays/s %.0f' % d['value'], 'kernel ms %.3f' % d['roofline']['ms_per_launch'])"
 }
 for spp in 64 32 16 8; do
-  run --workload c2 --spp $spp --steps 20 --warmup 3
+  run --workload c2 --spp $spp --steps 20 --warmup 3 --in-flight 1
+  run --workload c2 --spp $spp --steps 20 --warmup 3 --in-flight 1 --force-collective
+done
+# the bench's own choice of steps in flight (two when a step alone takes less than 8 ms)
+for spp in 64 32 16 8; do
   run --workload c2 --spp $spp --steps 20 --warmup 3 --force-collective
 done
 for spp in 1024 512 256 128; do
