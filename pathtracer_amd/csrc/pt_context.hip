@@ -27,6 +27,7 @@ struct pt_context {
     size_t n_wide_alloc = 0;
     uint32_t wide_depth = 0;
     PrimRec *d_prims = nullptr, *d_prims_list = nullptr;
+    uint32_t *d_cone_tab = nullptr; // the cones' distinct slopes (cone_table_hit), or null
     float4 *d_mats = nullptr;
     uint32_t max_depth_tree = 0;
     pt::BvhBuild tree;      // the installed scene's tree (host copy), refitted by pt_scene_update
@@ -176,8 +177,8 @@ extern "C" pt_status pt_context_configure(pt_context *ctx, const pt_tuning *t)
 
 static void free_scene(pt_context *ctx)
 {
-    hipFree(ctx->d_nodes); hipFree(ctx->d_prims); hipFree(ctx->d_prims_list); hipFree(ctx->d_mats); hipFree(ctx->d_wide);
-    ctx->d_wide = nullptr; ctx->n_wide_alloc = 0;
+    hipFree(ctx->d_nodes); hipFree(ctx->d_prims); hipFree(ctx->d_prims_list); hipFree(ctx->d_mats); hipFree(ctx->d_wide); hipFree(ctx->d_cone_tab);
+    ctx->d_wide = nullptr; ctx->n_wide_alloc = 0; ctx->d_cone_tab = nullptr;
     ctx->d_nodes = nullptr; ctx->d_prims = ctx->d_prims_list = nullptr; ctx->d_mats = nullptr;
     ctx->has_scene = false;
 }
@@ -349,6 +350,56 @@ extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *o
     return PT_OK;
 }
 
+// The table cone_table_hit() searches (layout there): the distinct tangens values of the scene's cones, as the list
+// records hold them, each with the largest list index that has it.  Values that are negative or not finite cancel no
+// ray's |d_xz|^2 and are left out.  Empty when the scene has no such cone.
+static std::vector<uint32_t> make_cone_table(const std::vector<PrimRec> &list)
+{
+    std::vector<std::pair<uint32_t, uint32_t>> v; // (bits of tangens, list index)
+    for (size_t i = 0; i < list.size(); ++i) {
+        if ((list[i].meta & 7u) != PT_CONE) continue;
+        uint32_t bits;
+        memcpy(&bits, &list[i].p[5], 4);
+        if (bits < 0x7F800000u) v.emplace_back(bits, (uint32_t)i); // +0 .. the largest finite value: their bit patterns order as they do
+    }
+    std::vector<uint32_t> tab;
+    if (v.empty()) return tab;
+    std::sort(v.begin(), v.end());
+    std::vector<uint32_t> val, idx;
+    for (const auto &e : v) {
+        if (!val.empty() && val.back() == e.first) idx.back() = e.second; // (sorted: the later pair has the larger index)
+        else { val.push_back(e.first); idx.push_back(e.second); }
+    }
+    const uint32_t n = (uint32_t)val.size(), lo = val.front(), hi = val.back();
+    uint32_t want = 1;
+    while (want < 2 * n && want < 65536u) want <<= 1;
+    uint32_t shift = 5; // a cell spans at least 32 bit patterns, so the candidates of a ray (+-PT_CONE_TAB_SLACK) touch at most two
+    while (((hi - lo) >> shift) >= want) ++shift;
+    const uint32_t nb = ((hi - lo) >> shift) + 1;
+    tab.assign(PT_CONE_TAB_HEADER + 4 * (size_t)nb + 2 * (size_t)n, 0u);
+    tab[0] = n; tab[1] = lo; tab[2] = hi; tab[3] = shift; tab[4] = nb;
+    float flo, fhi;
+    memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4);
+    flo *= 1.0f - 1.0f / 1024.0f; fhi *= 1.0f + 1.0f / 1024.0f; // the bounds of the test that needs no division
+    memcpy(&tab[5], &flo, 4); memcpy(&tab[6], &fhi, 4);
+    uint32_t *cells = tab.data() + PT_CONE_TAB_HEADER;
+    std::fill(cells, cells + 4 * (size_t)nb, PT_CONE_TAB_NONE);
+    for (uint32_t i = 0; i < n;) {
+        const uint32_t b = (val[i] - lo) >> shift;
+        uint32_t j = i;
+        while (j < n && ((val[j] - lo) >> shift) == b) ++j;
+        if (j - i > 2) {
+            cells[4 * b] = PT_CONE_TAB_MORE;
+        } else {
+            for (uint32_t k = i; k < j; ++k) { cells[4 * b + 2 * (k - i)] = val[k]; cells[4 * b + 2 * (k - i) + 1] = idx[k]; }
+        }
+        i = j;
+    }
+    memcpy(cells + 4 * (size_t)nb, val.data(), 4 * (size_t)n);
+    memcpy(cells + 4 * (size_t)nb + n, idx.data(), 4 * (size_t)n);
+    return tab;
+}
+
 // Copies a built (or refitted) tree and the scene's records to the device and points the context at them.  Everything
 // goes into new buffers first; the installed scene (if any) is replaced, and its buffers freed, only after every copy
 // has succeeded, so a failure leaves the context rendering what it rendered before.
@@ -374,11 +425,17 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     const bool want_wide = nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, 1) != 0;
     if (want_wide) pt::make_wide(b, wb);
 
+    const std::vector<uint32_t> cone_tab = make_cone_table(list);
     BvhNode *n_nodes = nullptr;
     PrimRec *n_prims = nullptr, *n_list = nullptr;
     float4 *n_mats = nullptr, *n_wide = nullptr;
+    uint32_t *n_cone_tab = nullptr;
     auto upload = [&]() -> hipError_t {
         hipError_t e;
+        if (!cone_tab.empty()) {
+            if ((e = hipMalloc(&n_cone_tab, cone_tab.size() * 4)) != hipSuccess) return e;
+            if ((e = hipMemcpy(n_cone_tab, cone_tab.data(), cone_tab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        }
         if ((e = hipMalloc(&n_nodes, nb)) != hipSuccess) return e;
         if ((e = hipMalloc(&n_prims, pb + sizeof(PrimRec))) != hipSuccess) return e; // one record of padding: k_paths_stream fetches objects in pairs
         if ((e = hipMalloc(&n_list, pb)) != hipSuccess) return e;
@@ -394,16 +451,18 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     };
     const hipError_t ue = upload();
     if (ue != hipSuccess) {
-        hipFree(n_nodes); hipFree(n_prims); hipFree(n_list); hipFree(n_mats); hipFree(n_wide);
+        hipFree(n_nodes); hipFree(n_prims); hipFree(n_list); hipFree(n_mats); hipFree(n_wide); hipFree(n_cone_tab);
         return fail(ctx, PT_ERR_DEVICE, std::string("scene upload: ") + hipGetErrorString(ue));
     }
     free_scene(ctx); // the previous scene's buffers
     ctx->d_nodes = n_nodes; ctx->d_prims = n_prims; ctx->d_prims_list = n_list; ctx->d_mats = n_mats; ctx->d_wide = n_wide;
+    ctx->d_cone_tab = n_cone_tab;
     ctx->n_mats_alloc = mats.size();
     ctx->n_wide_alloc = want_wide ? wb.nodes.size() : 0;
 
     SceneDev &sc = ctx->sc;
     sc.wide = n_wide;
+    sc.cone_tab = n_cone_tab;
     // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
     // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
     sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 2u) : 0u; // (with the bottom entry; 31 x 256 lanes x 4 B lets five workgroups share a CU's LDS)

@@ -105,18 +105,39 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                 h.t = nh.best_t;
                 h.slot = nh.best_slot;
                 bool scan_list = false;
+                uint32_t scan_from = 0; // the list entry a scan starts at
                 bool fresh = false; // this lane leaves the serve with a new ray (scattered, or the first of a new path)
                 if (to_shade) {
                     bool need_exact = by_list;
-                    settle_parked<CONES>(nh, need_exact);
+                    // Some cone's leading coefficient is exactly 0 for this direction (cone_table_hit): the scan accepts that cone
+                    // at t = NaN wherever it stands, and its answer is the scan's from that entry on -- the nearest of the later
+                    // entries by the scan's own rules, or the cone itself at t = NaN when the ray's line meets none of them.
+                    // (A traversal that met such a cone itself and stopped at the NaN, by_list, is answered the same way.)
+                    const bool from_cone = CONES && sc.cone_tab && cone_table_hit(sc.cone_tab, r.d, scan_from);
+                    if (!from_cone) {
+                        scan_from = 0;
+                        settle_parked<CONES>(nh, need_exact);
+                    }
                     h.t = nh.best_t;
                     h.slot = nh.best_slot;
-                    if (need_exact) {
-                        if (CONES && !by_list) {
-                            h = bvh_exact_scan<BLOCK>(gsrc, sc.stack_cap, r, br, t_min, t_max, stack, need_exact);
+                    if (from_cone || need_exact) {
+                        if (CONES && (from_cone || !by_list)) {
+                            h = bvh_exact_scan<BLOCK>(gsrc, sc.stack_cap, r, br, t_min, t_max, stack, need_exact, from_cone ? scan_from + 1u : 0u);
                             nr++;
+                            if (from_cone && !need_exact && h.slot == PT_NO_PRIM) {
+                                h.t = __builtin_nanf("");
+                                h.slot = scan_from | 0x80000000u;
+                            }
                         }
                         scan_list = need_exact; // by_list, or more candidates than the replay keeps
+                    }
+                    // A ray that is NaN in every component (what follows a hit at t = NaN: the point, and with it the scattered
+                    // direction) is accepted by every entry at t = NaN: none of the reference's tests can reject it, so the
+                    // scan ends on the list's last entry.  No need to run it.
+                    if (scan_list && r.o.x != r.o.x && r.o.y != r.o.y && r.o.z != r.o.z && r.d.x != r.d.x && r.d.y != r.d.y && r.d.z != r.d.z) {
+                        scan_list = false;
+                        h.t = r.o.x;
+                        h.slot = (sc.n_prims - 1u) | 0x80000000u;
                     }
                 }
                 // the list itself, one such ray at a time by the whole wave
@@ -124,8 +145,9 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     const int j = __ffsll((long long)m) - 1;
                     const float jox = __shfl(r.o.x, j, 64), joy = __shfl(r.o.y, j, 64), joz = __shfl(r.o.z, j, 64);
                     const float jdx = __shfl(r.d.x, j, 64), jdy = __shfl(r.d.y, j, 64), jdz = __shfl(r.d.z, j, 64);
-                    const unsigned long long hj = CONES ? wave_list_scan_call(sc.prims_list, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max)
-                                                        : wave_list_scan(sc.prims_list, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max);
+                    const uint32_t jfrom = CONES ? (uint32_t)__shfl((int)scan_from, j, 64) : 0u;
+                    const unsigned long long hj = CONES ? wave_list_scan_call(sc.prims_list, jfrom, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max)
+                                                        : wave_list_scan(sc.prims_list, 0u, sc.n_prims, jox, joy, joz, jdx, jdy, jdz, t_min, t_max);
                     if (lane == (uint32_t)j) {
                         h.t = __uint_as_float((uint32_t)hj);
                         h.slot = (uint32_t)(hj >> 32);

@@ -12,6 +12,10 @@
 #include "pt_device.h"
 
 #define PT_BLOCK 256
+// what a scene holds (the kernels' KIND parameter; see bvh_nearest)
+#define PT_KIND_SPHERES 0
+#define PT_KIND_NO_CONES 1
+#define PT_KIND_ANY 2
 #define PT_WAVES (PT_BLOCK / 64)
 
 // ---------------------------------------------------------------------------------------------
@@ -27,6 +31,7 @@ struct SceneDev {
     int32_t root_ref;   // the reference of the scene's only leaf where the tree is one (at most eight objects: the FLAT kernels start there), else 0
     const float4 *wide;      // the four-wide quantised form of the tree (pt::WideNode, 64 B each), for scenes traversed from HBM; or null
     uint32_t wide_stack_cap; // stack entries its traversal may use
+    const uint32_t *cone_tab; // the cones' distinct slopes, for cone_table_hit(); null for a scene without cones
     pt::ConeParams cone; // how wide a cone the slab test gives a ray
     DeviceCamera cam;
     float bg[3];
@@ -91,12 +96,12 @@ PT_DI bool hit_any(const PrimRec &q, const Ray &r, float t_min, float t_max, flo
 
 // hittable_list::hit (hittable_list.h:87-101) over the list-order records: the definition of the
 // answer.  Used by PT_TRACE_LINEAR and to resolve the rare rays whose answer depends on list order.
-PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, const Ray &r, float t_min, float t_max)
+PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, const Ray &r, float t_min, float t_max, uint32_t first = 0)
 {
     HitResult best;
     best.t = t_max;
     best.slot = PT_NO_PRIM;
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = first; i < n; ++i) {
         PrimRec q = list[i];
         float t;
         if (hit_any(q, r, t_min, best.t, t)) {
@@ -105,6 +110,84 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
         }
     }
     return best;
+}
+
+// A cone that every ray of one direction "hits", wherever it stands.  cone.h:108 computes the quadratic's leading
+// coefficient a = |d_xz|^2 - tangens d_y d_y; when the two terms round to the same float a is exactly 0, the
+// discriminant is half_b^2, one of the roots (cone.h:116-120) is 0 / 0 = NaN, and the reference's range and clip tests
+// (all of the form "reject if x < bound") let a NaN through: the cone is accepted at t = NaN by a ray that may pass
+// nowhere near it, and from that list entry on the scan accepts whatever the ray's line crosses, in list order.  About
+// one ray in 16 000 of the 100k mixed objects.  No tree can find such a cone by where it stands, but it can be found by
+// its slope: fl(fl(tangens d_y) d_y) is monotone in tangens, so the value that cancels a given ray lies within a few
+// units in the last place of q = |d_xz|^2 / d_y^2, and the scene's distinct tangens values are kept in a table keyed by
+// their bit patterns, each with the largest list index that has it.  Layout (uint32 words):
+//   [0] n values  [1] bits of the smallest  [2] bits of the largest  [3] shift (>= 5)  [4] cells B
+//   [5], [6] the smallest value times (1 - 2^-10) and the largest times (1 + 2^-10), as float bits
+//   [8 ..]  B cells of four words: (value, index, value, index) of the at most two values whose
+//           (bits - [1]) >> shift is the cell's number; unused entries hold PT_CONE_TAB_NONE, and a cell that would
+//           need more than two holds PT_CONE_TAB_MORE in its first word
+//   then the n values ascending (float bits) and their n list indices, for such cells.
+// Returns whether some cone's a is exactly 0 for direction d, and the largest list index of such a cone: the scan's
+// answer is then the scan's answer from that entry on (the entry is accepted whatever came before it, and with the
+// running t a NaN nothing that came before matters).  A range test on the ray alone comes first (no memory; three rays
+// in four end there on the 100k mixed objects), then one 16-byte load (two where the candidates straddle a cell boundary).
+// (A one-bit-per-16-patterns bitmap in front of the cells, its word asked for when the ray starts and looked at when the
+// traversal is over, was measured and is no faster: 100k mixed objects at 8 spp 71.5 against 70.7 ms.)
+#define PT_CONE_TAB_HEADER 8u
+#define PT_CONE_TAB_NONE 0xFFFFFFFFu
+#define PT_CONE_TAB_MORE 0xFFFFFFFEu
+#define PT_CONE_TAB_SLACK 8u // q is off by at most six bit patterns: d_y^2, the reciprocal, the product and the reference's two products round once each
+PT_DI bool cone_table_hit(const uint32_t *__restrict__ tab, v3 d, uint32_t &last_index)
+{
+    const float S = d.x * d.x + d.z * d.z; // |d_xz|^2 as vlen2 of (d_x, 0, d_z) rounds it (cone.h:108, vec3.h:154-156)
+    const float dy2 = d.y * d.y;
+    last_index = 0;
+    if (!(S >= dy2 * __uint_as_float(tab[5]) && S <= dy2 * __uint_as_float(tab[6]))) return false; // (a NaN ends here too)
+    const uint32_t lo = tab[1], span = tab[2] - lo, shift = tab[3];
+    const uint32_t key = min(max(__float_as_uint(S * __builtin_amdgcn_rcpf(dy2)), lo), tab[2]) - lo;
+    const uint32_t b0 = (key > PT_CONE_TAB_SLACK ? key - PT_CONE_TAB_SLACK : 0u) >> shift, b1 = min(key + PT_CONE_TAB_SLACK, span) >> shift;
+    const uint4 *cells = reinterpret_cast<const uint4 *>(tab + PT_CONE_TAB_HEADER);
+    const uint4 c0 = cells[b0];
+    bool found = false;
+    auto check = [&](uint32_t vbits, uint32_t index) { // tangens * r.d.y * r.d.y against |d_xz|^2, cone.h:108
+        if ((__uint_as_float(vbits) * d.y) * d.y == S) { // (PT_CONE_TAB_NONE is a NaN: never equal)
+            found = true;
+            last_index = max(last_index, index);
+        }
+    };
+    check(c0.x, c0.y); check(c0.z, c0.w);
+    uint4 c1 = c0;
+    if (b1 != b0) { // the candidates straddle a cell boundary (b1 = b0 + 1: a cell is at least 32 bit patterns wide)
+        c1 = cells[b1];
+        check(c1.x, c1.y); check(c1.z, c1.w);
+    }
+    if (c0.x == PT_CONE_TAB_MORE || c1.x == PT_CONE_TAB_MORE) { // a crowded cell: the sorted values
+        const uint32_t n = tab[0], nb = tab[4];
+        const float *val = reinterpret_cast<const float *>(tab + PT_CONE_TAB_HEADER + 4u * (size_t)nb);
+        const uint32_t *index = reinterpret_cast<const uint32_t *>(val + n);
+        uint32_t i0 = 0, i1 = n;
+        while (i0 < i1) { // the first value whose term is not below S
+            const uint32_t mid = (i0 + i1) >> 1;
+            if ((val[mid] * d.y) * d.y < S) i0 = mid + 1u;
+            else i1 = mid;
+        }
+        for (; i0 < n && (val[i0] * d.y) * d.y == S; ++i0) {
+            found = true;
+            last_index = max(last_index, index[i0]);
+        }
+    }
+    return found;
+}
+
+// After the tree walk of a scene with cones: the list entry the scan has to start at for this ray (and need_exact set)
+// when some cone's leading coefficient is exactly 0 for it, else 0 and need_exact as it was.
+template <int KIND>
+PT_DI uint32_t cone_scan_from(const SceneDev &sc, const Ray &r, bool &need_exact)
+{
+    uint32_t from = 0;
+    if (KIND == PT_KIND_ANY && sc.cone_tab && cone_table_hit(sc.cone_tab, r.d, from)) need_exact = true;
+    else from = 0;
+    return from;
 }
 
 // The reference's hit arithmetic is fp32 on unnormalised rays, and what it ACCEPTS is not exactly the
@@ -388,10 +471,11 @@ static size_t lds_scene_size(uint32_t n_nodes, uint32_t n_prims)
 // [t_min, t_max] and passes its clip; one traversal WITHOUT nearest-hit pruning collects those
 // objects (a handful: the surfaces the ray really crosses), they are ordered by list index, and
 // hittable_list::hit (hittable_list.h:87-101) is replayed over them.  `overflow` is set when more
-// than PT_SCAN_MAX candidates exist (the caller then scans the whole list).
+// than PT_SCAN_MAX candidates exist (the caller then scans the whole list).  `first`: only list entries from this
+// index on count (the scan of a ray that a cone accepts at t = NaN whatever came before: cone_table_hit).
 template <int STRIDE, class Src>
 static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &src, uint32_t stack_cap, const Ray &r, const BoxRay &br, float t_min, float t_max,
-                               uint32_t *stack, bool &overflow)
+                               uint32_t *stack, bool &overflow, uint32_t first = 0)
 {
     uint32_t ids[PT_SCAN_MAX], slots[PT_SCAN_MAX];
     int n = 0;
@@ -401,6 +485,7 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
     if (steep) sb = make_steep_bounds(r, ray_kappa(src.cone, r.o));
     uint32_t sp = 0;
     int32_t cur = 0;
+    const uint32_t first_id = first; // (the leaf loop below has a `first` of its own)
     for (;;) {
         if (cur >= 0) {
             float2 nx, ny, nz, fx, fy, fz;
@@ -442,7 +527,7 @@ static __device__ __attribute__((noinline)) HitResult bvh_exact_scan(const Src &
                 } else {
                     possible = hit_any(q, r, t_min, t_max, t);
                 }
-                if (possible) {
+                if (possible && q.id >= first_id) {
                     if (n == PT_SCAN_MAX) { overflow = true; continue; }
                     int at = n++;
                     while (at > 0 && ids[at - 1] > q.id) { ids[at] = ids[at - 1]; slots[at] = slots[at - 1]; --at; }
@@ -657,9 +742,6 @@ PT_DI void settle_parked(Nearest &nh, bool &need_exact)
 //                    a = |d|^2 > 0 for every ray a render produces);
 //   PT_KIND_NO_CONES any objects but cones: nothing list-order dependent;
 //   PT_KIND_ANY      everything.
-#define PT_KIND_SPHERES 0
-#define PT_KIND_NO_CONES 1
-#define PT_KIND_ANY 2
 template <bool COUNT, int KIND, int STRIDE, class Src, bool FLAT = false /* the scene is one leaf, `root` its reference: no tree code at all */>
 PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, float t_min, float t_max,
                             uint32_t *stack /* [sp*STRIDE] */, bool &need_exact, uint32_t &n_box, uint32_t &n_prim, uint32_t &n_replay,
@@ -862,8 +944,8 @@ PT_DI unsigned long long wave_sum_u32(uint32_t v)
 // (a hit whose t is NaN is accepted by the reference's comparisons, and so is everything after it)
 // no test depends on it any more: all accepting lanes up to the first one with an ordinary t are then
 // what the scan accepts, and one round settles them.  All 64 lanes must call this together.
-static __device__ __forceinline__ unsigned long long wave_list_scan(const PrimRec *__restrict__ list, uint32_t n, float ox, float oy, float oz, float dx, float dy, float dz,
-                                                                 float t_min, float t_max)
+static __device__ __forceinline__ unsigned long long wave_list_scan(const PrimRec *__restrict__ list, uint32_t first /* the entry the scan starts at */, uint32_t n, float ox, float oy,
+                                                                 float oz, float dx, float dy, float dz, float t_min, float t_max)
 {
     Ray r;
     r.o = V(ox, oy, oz);
@@ -872,7 +954,7 @@ static __device__ __forceinline__ unsigned long long wave_list_scan(const PrimRe
     HitResult best; // wave-uniform
     best.t = t_max;
     best.slot = PT_NO_PRIM;
-    for (uint32_t base = 0; base < n; base += 64u) {
+    for (uint32_t base = first; base < n; base += 64u) {
         const bool valid = base + lane < n;
         const PrimRec q = list[valid ? base + lane : base];
         uint32_t start = 0;
@@ -899,10 +981,10 @@ static __device__ __forceinline__ unsigned long long wave_list_scan(const PrimRe
 // The same as a call.  Which form costs the calling kernel less is a matter of its register allocation:
 // k_paths_stream takes the call where its cone code already fills the register file (100k mixed objects:
 // 0.89 against 0.59 Grays/s inlined) and the inlined body otherwise (1M spheres: 1.07 against 0.95).
-static __device__ __attribute__((noinline)) unsigned long long wave_list_scan_call(const PrimRec *__restrict__ list, uint32_t n, float ox, float oy, float oz, float dx, float dy,
-                                                                                 float dz, float t_min, float t_max)
+static __device__ __attribute__((noinline)) unsigned long long wave_list_scan_call(const PrimRec *__restrict__ list, uint32_t first, uint32_t n, float ox, float oy, float oz, float dx,
+                                                                                 float dy, float dz, float t_min, float t_max)
 {
-    return wave_list_scan(list, n, ox, oy, oz, dx, dy, dz, t_min, t_max);
+    return wave_list_scan(list, first, n, ox, oy, oz, dx, dy, dz, t_min, t_max);
 }
 
 

@@ -610,6 +610,100 @@ def test_path_through_a_nan_hit_is_answered_by_the_list(ctx):
     assert s2["rays"] == rays and s2["exact_fallbacks"] >= w * h * spp and np.array_equal(img.view(np.uint32), got.view(np.uint32))
 
 
+def _with_cancelling_cones(src, positions, tangens=0.25):
+    """A copy of a scene's arrays with cones of the given tangens (radius / height squared, cone.h:30) at the given
+    list positions, far outside the rest of the scene."""
+    a = {k: v.copy() for k, v in src.arrays().items()}
+    for k, pos in enumerate(positions):
+        a["prim_type"][pos] = api.CONE
+        r = np.sqrt(np.float32(tangens)) * np.float32(2.0)
+        a["prim_param"][pos] = [500.0 + 10.0 * k, -300.0, 800.0, 2.0, r, tangens]
+    return a
+
+
+@pytest.mark.parametrize("where", ["first", "middle", "last", "two"])
+def test_cone_whose_leading_coefficient_cancels(ctx, where):
+    """cone.h:108 computes a = |d_xz|^2 - tangens d_y d_y.  For a direction whose two terms are the same float a is
+    exactly 0, the quadratic's roots (cone.h:116-120) are -inf and 0 / 0, and the NaN passes every test of the form
+    `x < bound` (the range tests, the clip of cone.h:121-123): the cone is hit at t = NaN by a ray that passes nowhere
+    near it, and hittable_list::hit (hittable_list.h:87-101) goes on from a running t of NaN.  The answer is then the
+    list's from that entry on.  The directions here are (3, 10, 4), (5, 26, 12), (8, 34, 15) with signs, swaps and
+    exact scalings: |d_xz|^2 = d_y^2 / 4 exactly, against cones of tangens 1/4 that stand 900 units from everything
+    else.  Tree walk, list scan and oracle must agree on every ray, NaN hits included."""
+    n = 400
+    src = scenes.mixed_scene(n=n, extent=20.0, seed=3)
+    positions = {"first": [0], "middle": [n // 2], "last": [n - 1], "two": [5, n - 7]}[where]
+    a = _with_cancelling_cones(src, positions)
+    b = scenes.ArrayScene(a, src.background, src.camera_args)
+    osc = util.oracle_scene(b)
+    ctx.upload(b.desc())
+    rng = np.random.Generator(np.random.PCG64(17))
+    m = 30000
+    base = np.array([[3, 10, 4], [5, 26, 12], [8, 34, 15]], dtype=np.float32)[rng.integers(0, 3, m)]
+    swap = rng.random(m) < 0.5
+    base[swap] = base[swap][:, [2, 1, 0]]
+    base *= rng.choice([-1.0, 1.0], (m, 3)).astype(np.float32)
+    d = (base * rng.choice([0.125, 0.5, 1.0, 3.0, 64.0], (m, 1)).astype(np.float32)).astype(np.float32)
+    o = (rng.random((m, 3)) * 20.0).astype(np.float32)
+    # and as many ordinary rays
+    o2, d2 = util.box_rays((0, 0, 0), (20, 20, 20), m, rng)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    want = osc.trace(o, d)
+    assert (want["nan_flag"][:m] & 1).all()  # every one of the built rays meets the NaN
+    nan_final = np.isnan(want["t"][:m])
+    if where == "last":
+        assert nan_final.all() and (want["prim"][:m] == n - 1).all()  # whatever else the ray hits: the last entry's NaN stands
+    else:
+        assert 0 < nan_final.sum() < m  # some rays cross a later entry (which then is the answer), some do not
+    for mode in (api.TRACE_LINEAR, api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
+        got = ctx.trace(o, d, mode=mode)
+        bad = util.hits_equal(got, want, nan_equal=True)
+        assert not bad[:m].any(), (mode, int(bad[:m].sum()))
+        assert not (bad[m:] & (want["nan_flag"][m:] == 0)).any(), mode
+        assert mode == api.TRACE_LINEAR or (got["flags"][:m] & 1).all()  # answered by the list, from that entry on
+
+
+@pytest.mark.parametrize("n", [300, 3000])
+def test_render_through_a_cancelling_cone(ctx, n):
+    """The same in a render: a camera whose field of view underflows sends every primary ray along exactly the same
+    direction, and a cone far behind the camera, in the middle of the list, has the tangens that cancels it.  The
+    reference's image then shows the later half of the list only (and where a ray meets none of it, a path that goes on
+    from a NaN point: every entry accepts such a ray, the last one stands, fifty bounces end in black).  300 objects
+    are rendered from LDS (k_paths_ring, k_paths), 3000 by the streaming kernel; all against the oracle."""
+    src = scenes.mixed_scene(n=n, extent=30.0, seed=9)
+    cam = ((15.0, 15.0, 60.0), (12.0, 11.0, 60.0), (0, 1, 0), 1e-30, 1.0, 0.0, 10.0)  # every ray along exactly (-6, -8, 0)
+    b0 = scenes.ArrayScene({k: v.copy() for k, v in src.arrays().items()}, src.background, cam)
+    o, d = util.oracle_scene(b0).get_ray(np.float32(0.5), np.float32(0.5), (0.0, 0.0))
+    d = np.asarray(d, dtype=np.float32)
+    S = np.float32(d[0] * d[0]) + np.float32(d[2] * d[2])
+    guess = np.float32(S / np.float32(d[1] * d[1]))
+    tangens = None
+    for step in range(-8, 9):  # the float whose term cancels |d_xz|^2 exactly, next to the quotient
+        t = guess
+        for _ in range(abs(step)):
+            t = np.nextafter(t, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+        if np.float32(np.float32(t * d[1]) * d[1]) == S:
+            tangens = t
+    assert tangens is not None
+    a = _with_cancelling_cones(src, [n // 2], tangens=float(tangens))
+    b = scenes.ArrayScene(a, src.background, cam)
+    osc = util.oracle_scene(b)
+    w, h, spp, depth = 8, 8, 4, 50
+    ref, rays = osc.render(w, h, spp, depth)
+    ctx.upload(b.desc())
+    first = osc.trace(np.asarray(o, dtype=np.float32).reshape(1, 3), d.reshape(1, 3))
+    assert first["nan_flag"][0] & 1
+    plain, _ = ctx.render(w, h, spp, depth, flags=0)
+    frac, rmse = _image_close(plain, ref)
+    assert frac == 0 and rmse < 2e-3, (frac, rmse)
+    for tune in ({}, {"pipeline": 0}, {"pipeline": 1}):
+        with ctx.tuned(**tune):
+            got, st = ctx.render(w, h, spp, depth)
+        assert st["rays"] == rays and np.isfinite(got).all(), (tune, st["rays"], rays)
+        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), tune
+        assert st["exact_fallbacks"] + st["exact_replays"] >= w * h * spp, tune  # every primary ray went the special way
+
+
 @pytest.mark.parametrize("which", ["spheres", "mixed"])
 def test_views_along_a_coordinate_axis(ctx, which):
     """A camera looking straight down the z axis through a 0.05 degree lens: every primary ray runs almost parallel
