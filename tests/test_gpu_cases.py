@@ -704,6 +704,32 @@ def test_render_through_a_cancelling_cone(ctx, n):
         assert st["exact_fallbacks"] + st["exact_replays"] >= w * h * spp, tune  # every primary ray went the special way
 
 
+def test_mixed_objects_tree_equals_scan_on_every_ray(ctx):
+    """The 100k mixed objects (25 000 cones of as many slopes): one scattered ray in 16 000 has a direction for which some
+    cone's leading coefficient cancels exactly, wherever that cone stands.  The tree walk must return the list scan's
+    record for every ray of three generations leaving the hit points of a million camera rays -- no mask."""
+    b = scenes.mixed_scene()
+    ctx.upload(b.desc())
+    rng = np.random.Generator(np.random.PCG64(5))
+    m = 1000000
+    eye = np.array(b.camera_args[0], dtype=np.float64)
+    o = np.ascontiguousarray(np.broadcast_to(eye, (m, 3)), dtype=np.float32)
+    d = np.ascontiguousarray(rng.random((m, 3)) * 200.0 - eye, dtype=np.float32)
+    nan_hits = 0
+    for gen in range(4):
+        tree = ctx.trace(o, d)
+        scan = ctx.trace(o, d, mode=api.TRACE_LINEAR)
+        bad = util.hits_equal(tree, scan, nan_equal=True)
+        assert not bad.any(), (gen, int(bad.sum()))
+        nan_hits += int(np.isnan(scan["t"]).sum())
+        hit = (scan["prim"] != api.NO_PRIM) & ~np.isnan(scan["t"])
+        r = rng.standard_normal((int(hit.sum()), 3))
+        r /= np.linalg.norm(r, axis=1, keepdims=True)
+        o = np.ascontiguousarray(scan["p"][hit], dtype=np.float32)
+        d = np.ascontiguousarray(scan["n"][hit] + r, dtype=np.float32)
+    assert nan_hits > 20  # (56 with this seed: the case is there)
+
+
 @pytest.mark.parametrize("which", ["spheres", "mixed"])
 def test_views_along_a_coordinate_axis(ctx, which):
     """A camera looking straight down the z axis through a 0.05 degree lens: every primary ray runs almost parallel
