@@ -93,6 +93,25 @@ def differing(g, h):
     return bad
 
 
+def explain(arrays, o, d, prim):
+    """What the quadratic of the object the scan hit looks like for this ray (fp32, as cone.h:101-112 computes it)."""
+    f = np.float32
+    t = int(arrays["prim_type"][prim])
+    p = arrays["prim_param"][prim].astype(np.float32)
+    if t != api.CONE:
+        return "object %d type %d params %s" % (prim, t, p.tolist())
+    oc = (o - p[:3]).astype(np.float32)
+    D = f(f(p[3] - o[1]) + p[1])
+    sxz = f(f(d[0] * d[0]) + f(d[2] * d[2]))
+    tdy = f(f(p[5] * d[1]) * d[1])
+    a = f(sxz - tdy)
+    hb = f(f(f(oc[0] * d[0]) + f(oc[2] * d[2])) + f(f(p[5] * d[1]) * D))
+    c = f(f(f(oc[0] * oc[0]) + f(oc[2] * oc[2])) - f(f(p[5] * D) * D))
+    disc = f(f(hb * hb) - f(a * c))
+    return "cone %d height %g radius %g tangens %g: a = %g (its terms %g: %.1f units in the last place), half_b %g c %g discriminant %g (half_b^2 %g)" % (
+        prim, p[3], p[4], p[5], a, sxz, abs(float(a)) / float(np.spacing(sxz)), hb, c, disc, f(hb * hb))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -118,6 +137,8 @@ def main():
             for i in np.flatnonzero(bad)[:3]:
                 print("    gen %d ray o=%s d=%s scan t=%r prim=%d flags=%d | tree t=%r prim=%d flags=%d" % (
                     gen, o[i].tolist(), d[i].tolist(), scan["t"][i], scan["prim"][i], scan["flags"][i], tree["t"][i], tree["prim"][i], tree["flags"][i]))
+                if scan["prim"][i] != api.NO_PRIM:
+                    print("        " + explain(b.arrays(), o[i], d[i], int(scan["prim"][i])))
             if hit.sum() < 100:
                 break
             p = scan["p"][hit]
