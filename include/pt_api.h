@@ -106,13 +106,16 @@ typedef struct pt_stats {
     uint64_t rays;         /* nearest-hit queries: one per (*world)->hit call at main.cu:54 */
     uint64_t primary_rays;
     uint64_t box_tests, prim_tests; /* only with PT_RENDER_COUNT_TESTS */
-    uint64_t exact_fallbacks;       /* rays resolved by the full list-order scan (more than 16 candidate objects) */
+    uint64_t exact_fallbacks;       /* rays resolved by a list-order scan of the objects: a hit at t = NaN, a non-finite ray, more than 16
+                                       candidate objects, or (scenes traversed from on-chip memory) a cone whose quadratic's leading
+                                       coefficient is exactly 0 for the ray, cone.h:108 */
     double ms_total;                /* device time of the whole call (events on the call's stream) */
     double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES | PT_RENDER_SPLIT_KERNELS */
     uint32_t launches_intersect; /* launches of the dominant kernel (k_intersect, or k_paths) */
     uint32_t passes;
     double ms_paths; /* only with PT_RENDER_STAGE_TIMES: summed k_paths launch time */
-    uint64_t exact_replays; /* rays whose list-order dependent answer was replayed over their candidate objects */
+    uint64_t exact_replays; /* rays whose list-order dependent answer was replayed over their candidate objects (a cone with a < 0,
+                               cone.h:116-120; in the streaming kernel also the rays of the cancelling cones above) */
     uint32_t kernel;        /* which pipeline rendered the call: PT_KERNEL_* */
     uint32_t reserved;
 } pt_stats;
