@@ -141,6 +141,36 @@ def test_list_scan_order_dependence_of_steep_cone():
     assert h["prim"] == 1 and h["t"] == 2.5  # ceiling first: t_max = 3.25 < 3.5, so the cone's real root is accepted
 
 
+def test_cone_whose_leading_coefficient_cancels_accepts_every_such_ray():
+    """cone.h:108: a = |d_xz|^2 - tangens d_y d_y.  With tangens 1/4 and d = (3, 10, 4) both terms are exactly 25, so
+    a = 0 whatever the origin: the discriminant is half_b^2, (-half_b - sqrtd) / 0 is -inf or 0 / 0 and
+    (-half_b + sqrtd) / 0 is 0 / 0 or +inf (cone.h:116-120).  -inf fails `root < t_min`; a NaN fails no test, not the
+    range tests and not the clip of cone.h:121-123: the cone, 900 units away from the ray, is hit at t = NaN.
+    hittable_list::hit (hittable_list.h:87-101) then carries closest_so_far = NaN: a later entry is accepted wherever the
+    ray's line crosses it, an earlier hit is overwritten."""
+    def scene(order):
+        b = scenes.SceneBuilder()
+        m = b.lambertian((0.5, 0.5, 0.5))
+        for what in order:
+            if what == "cone":
+                b.cone((500.0, -300.0, 800.0), 2.0, 1.0, m)  # tangens (1 / 2)^2
+            else:
+                b.sphere((3.0, 10.0, 4.0), 1.0, m)  # on the ray's line, at t = 1 -+ 1 / sqrt(125)
+        b.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+        return one(b)
+    o, d = [[0.0, 0.0, 0.0]], [[3.0, 10.0, 4.0]]
+    hit, r = scene(["cone"]).hit_prim(0, o[0], d[0])
+    assert hit and np.isnan(r["t"])
+    h = scene(["cone"]).trace(o, d)[0]
+    assert h["prim"] == 0 and np.isnan(h["t"]) and h["nan_flag"] & 1
+    h = scene(["cone", "sphere"]).trace(o, d)[0]  # the later sphere takes over from the NaN
+    assert h["prim"] == 1 and abs(h["t"] - (1.0 - 1.0 / np.sqrt(125.0))) < 1e-6
+    h = scene(["sphere", "cone"]).trace(o, d)[0]  # the sphere is hit first -- and overwritten by the cone's NaN
+    assert h["prim"] == 1 and np.isnan(h["t"])
+    h = scene(["sphere", "cone"]).trace(o, [[3.0, 10.0, 4.5]])[0]  # another direction: a != 0, the far cone is missed
+    assert h["prim"] != 1 and not np.isnan(h["t"])
+
+
 def test_ties_go_to_the_later_list_index():
     b = scenes.SceneBuilder()
     m = b.lambertian((0.5, 0.5, 0.5))
