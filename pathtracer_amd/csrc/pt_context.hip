@@ -372,7 +372,7 @@ static std::vector<uint32_t> make_cone_table(const std::vector<PrimRec> &list)
     }
     const uint32_t n = (uint32_t)val.size(), lo = val.front(), hi = val.back();
     uint32_t want = 1;
-    while (want < 2 * n && want < 65536u) want <<= 1;
+    while (want < 2 * n && want < (1u << 21)) want <<= 1; // (two cells per value, 32 MiB of cells at most: a million slopes)
     uint32_t shift = 5; // a cell spans at least 32 bit patterns, so the candidates of a ray (+-PT_CONE_TAB_SLACK) touch at most two
     while (((hi - lo) >> shift) >= want) ++shift;
     const uint32_t nb = ((hi - lo) >> shift) + 1;
