@@ -351,8 +351,8 @@ extern "C" pt_status pt_scene_ray_cone(const pt_scene_desc *desc, pt_ray_cone *o
 }
 
 // The table cone_table_hit() searches (layout there): the distinct tangens values of the scene's cones, as the list
-// records hold them, each with the largest list index that has it.  Values that are negative or not finite cancel no
-// ray's |d_xz|^2 and are left out.  Empty when the scene has no such cone.
+// records hold them, each with its rank, the largest list index that has it and all the list indices that have it.
+// Values that are negative or not finite cancel no ray's |d_xz|^2 and are left out.  Empty when the scene has no such cone.
 static std::vector<uint32_t> make_cone_table(const std::vector<PrimRec> &list)
 {
     std::vector<std::pair<uint32_t, uint32_t>> v; // (bits of tangens, list index)
@@ -365,19 +365,21 @@ static std::vector<uint32_t> make_cone_table(const std::vector<PrimRec> &list)
     std::vector<uint32_t> tab;
     if (v.empty()) return tab;
     std::sort(v.begin(), v.end());
-    std::vector<uint32_t> val, idx;
-    for (const auto &e : v) {
-        if (!val.empty() && val.back() == e.first) idx.back() = e.second; // (sorted: the later pair has the larger index)
-        else { val.push_back(e.first); idx.push_back(e.second); }
+    const uint32_t m = (uint32_t)v.size();
+    std::vector<uint32_t> val, last, first;
+    for (uint32_t k = 0; k < m; ++k) {
+        if (val.empty() || val.back() != v[k].first) { val.push_back(v[k].first); last.push_back(v[k].second); first.push_back(k); }
+        else last.back() = v[k].second; // (sorted: the later pair has the larger index)
     }
+    first.push_back(m);
     const uint32_t n = (uint32_t)val.size(), lo = val.front(), hi = val.back();
     uint32_t want = 1;
     while (want < 2 * n && want < (1u << 21)) want <<= 1; // (two cells per value, 32 MiB of cells at most: a million slopes)
-    uint32_t shift = 5; // a cell spans at least 32 bit patterns, so the candidates of a ray (+-PT_CONE_TAB_SLACK) touch at most two
+    uint32_t shift = 7; // a cell spans at least 128 bit patterns, so the candidates of a ray (+-PT_CONE_TAB_SLACK) touch at most two
     while (((hi - lo) >> shift) >= want) ++shift;
     const uint32_t nb = ((hi - lo) >> shift) + 1;
-    tab.assign(PT_CONE_TAB_HEADER + 4 * (size_t)nb + 2 * (size_t)n, 0u);
-    tab[0] = n; tab[1] = lo; tab[2] = hi; tab[3] = shift; tab[4] = nb;
+    tab.assign(PT_CONE_TAB_HEADER + 4 * (size_t)nb + 3 * (size_t)n + 1 + m, 0u);
+    tab[0] = n; tab[1] = lo; tab[2] = hi; tab[3] = shift; tab[4] = nb; tab[7] = m;
     float flo, fhi;
     memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4);
     flo *= 1.0f - 1.0f / 1024.0f; fhi *= 1.0f + 1.0f / 1024.0f; // the bounds of the test that needs no division
@@ -391,12 +393,15 @@ static std::vector<uint32_t> make_cone_table(const std::vector<PrimRec> &list)
         if (j - i > 2) {
             cells[4 * b] = PT_CONE_TAB_MORE;
         } else {
-            for (uint32_t k = i; k < j; ++k) { cells[4 * b + 2 * (k - i)] = val[k]; cells[4 * b + 2 * (k - i) + 1] = idx[k]; }
+            for (uint32_t k = i; k < j; ++k) { cells[4 * b + 2 * (k - i)] = val[k]; cells[4 * b + 2 * (k - i) + 1] = k; }
         }
         i = j;
     }
-    memcpy(cells + 4 * (size_t)nb, val.data(), 4 * (size_t)n);
-    memcpy(cells + 4 * (size_t)nb + n, idx.data(), 4 * (size_t)n);
+    uint32_t *out = cells + 4 * (size_t)nb;
+    memcpy(out, val.data(), 4 * (size_t)n);
+    memcpy(out + n, last.data(), 4 * (size_t)n);
+    memcpy(out + 2 * (size_t)n, first.data(), 4 * ((size_t)n + 1));
+    for (uint32_t k = 0; k < m; ++k) out[3 * (size_t)n + 1 + k] = v[k].second;
     return tab;
 }
 

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths(SceneDev sc, PassDev ps, Sli
         const int32_t root_ref = FLAT ? sc.root_ref : 0; // (a run-time start reference in the kernels with tree code costs them 0.5 %)
         if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK, LdsSrc, FLAT>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
         else h = bvh_nearest<COUNT, KIND, BLOCK, GlobalSrc, FLAT>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
-        const uint32_t scan_from = cone_scan_from<KIND>(sc, r, need_exact);
+        const uint32_t scan_from = cone_scan_from<KIND>(sc, r, t_min, t_max, need_exact);
         if (need_exact) {
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max, scan_from);
             if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;

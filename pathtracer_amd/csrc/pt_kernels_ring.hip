@@ -191,7 +191,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_paths_ring(SceneDev sc, PassDev ps
                 const int32_t root_ref = FLAT ? sc.root_ref : 0;
                 if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK, LdsSrc, FLAT>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
                 else h = bvh_nearest<COUNT, KIND, BLOCK, GlobalSrc, FLAT>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr, &prof, root_ref);
-                const uint32_t scan_from = cone_scan_from<KIND>(sc, r, need_exact);
+                const uint32_t scan_from = cone_scan_from<KIND>(sc, r, t_min, t_max, need_exact);
                 if (need_exact) { // resolved on the list-order records; the top bit of the slot says which array it indexes
                     h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max, scan_from);
                     if (h.slot != PT_NO_PRIM) h.slot |= 0x80000000u;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(SceneDev sc, const float *__
                 flags = 2;
                 atomicAdd(&cnt->exact_replays, 1ull);
             }
-            const uint32_t scan_from = cone_scan_from<PT_KIND_ANY>(sc, r, need_exact);
+            const uint32_t scan_from = cone_scan_from<PT_KIND_ANY>(sc, r, t_min, t_max, need_exact);
             if (need_exact) {
                 h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max, scan_from);
                 arr = sc.prims_list;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, PathPlanes st,
         if (LDS) h = bvh_nearest<COUNT, KIND, BLOCK>(lsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         else h = bvh_nearest<COUNT, KIND, BLOCK>(gsrc, sc.stack_cap, r, t_min, t_max, s_stack + threadIdx.x, need_exact, nb, np, nr);
         uint32_t slot = h.slot;
-        const uint32_t scan_from = cone_scan_from<KIND>(sc, r, need_exact);
+        const uint32_t scan_from = cone_scan_from<KIND>(sc, r, t_min, t_max, need_exact);
         if (need_exact) {
             // resolved on the list-order records; the top bit of the slot says which array it indexes
             h = linear_nearest(sc.prims_list, sc.n_prims, r, t_min, t_max, scan_from);

@@ -113,15 +113,19 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     // at t = NaN wherever it stands, and its answer is the scan's from that entry on -- the nearest of the later
                     // entries by the scan's own rules, or the cone itself at t = NaN when the ray's line meets none of them.
                     // (A traversal that met such a cone itself and stopped at the NaN, by_list, is answered the same way.)
-                    const bool from_cone = CONES && sc.cone_tab && cone_table_hit(sc.cone_tab, r.d, scan_from);
-                    if (!from_cone) {
-                        scan_from = 0;
-                        settle_parked<CONES>(nh, need_exact);
-                    }
+                    // Or some cone's coefficient has all but cancelled and its roots, which are rounding noise, pass its tests:
+                    // then the list itself answers (from the start, or from the cone of the first case on).
+                    uint32_t near_lo = 0, near_hi = 0;
+                    const uint32_t found = CONES && sc.cone_tab ? cone_table_hit(sc.cone_tab, r.d, scan_from, near_lo, near_hi) : 0u;
+                    const bool near_ok = (found & 2u) && cone_near_acceptable(sc.cone_tab, sc.prims_list, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max, near_lo, near_hi);
+                    const bool from_cone = (found & 1u) && !near_ok;
+                    if (!(found & 1u)) scan_from = 0;
+                    if (near_ok) need_exact = true;
+                    else if (!from_cone) settle_parked<CONES>(nh, need_exact);
                     h.t = nh.best_t;
                     h.slot = nh.best_slot;
                     if (from_cone || need_exact) {
-                        if (CONES && (from_cone || !by_list)) {
+                        if (CONES && !near_ok && (from_cone || !by_list)) {
                             h = bvh_exact_scan<BLOCK>(gsrc, sc.stack_cap, r, br, t_min, t_max, stack, need_exact, from_cone ? scan_from + 1u : 0u);
                             nr++;
                             if (from_cone && !need_exact && h.slot == PT_NO_PRIM) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                                 h.slot = scan_from | 0x80000000u;
                             }
                         }
-                        scan_list = need_exact; // by_list, or more candidates than the replay keeps
+                        scan_list = need_exact; // by_list, a nearly cancelled cone, or more candidates than the replay keeps
                     }
                     // A ray that is NaN in every component (what follows a hit at t = NaN: the point, and with it the scattered
                     // direction) is accepted by every entry at t = NaN: none of the reference's tests can reject it, so the

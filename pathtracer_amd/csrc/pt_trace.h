@@ -112,82 +112,120 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
     return best;
 }
 
-// A cone that every ray of one direction "hits", wherever it stands.  cone.h:108 computes the quadratic's leading
-// coefficient a = |d_xz|^2 - tangens d_y d_y; when the two terms round to the same float a is exactly 0, the
-// discriminant is half_b^2, one of the roots (cone.h:116-120) is 0 / 0 = NaN, and the reference's range and clip tests
-// (all of the form "reject if x < bound") let a NaN through: the cone is accepted at t = NaN by a ray that may pass
-// nowhere near it, and from that list entry on the scan accepts whatever the ray's line crosses, in list order.  About
-// one ray in 16 000 of the 100k mixed objects.  No tree can find such a cone by where it stands, but it can be found by
-// its slope: fl(fl(tangens d_y) d_y) is monotone in tangens, so the value that cancels a given ray lies within a few
-// units in the last place of q = |d_xz|^2 / d_y^2, and the scene's distinct tangens values are kept in a table keyed by
-// their bit patterns, each with the largest list index that has it.  Layout (uint32 words):
-//   [0] n values  [1] bits of the smallest  [2] bits of the largest  [3] shift (>= 5)  [4] cells B
+// Cones that a ray "hits" wherever they stand.  cone.h:108 computes the quadratic's leading coefficient
+// a = |d_xz|^2 - tangens d_y d_y.
+//  * When the two terms round to the same float a is exactly 0, the discriminant is half_b^2, one of the roots
+//    (cone.h:116-120) is 0 / 0 = NaN, and the reference's range and clip tests (all of the form "reject if x < bound") let
+//    a NaN through: the cone is accepted at t = NaN by a ray that may pass nowhere near it, and from that list entry on
+//    the scan accepts whatever the ray's line crosses, in list order.  About one ray in 16 000 of the 100k mixed objects.
+//  * When they differ by a unit or two in the last place, a is a few 2^-24ths of its terms, the roots are the rounding
+//    noise of -half_b -+ sqrtd divided by it -- a ratio of small integers times a power of two: 0.5, 6, 768 -- and now and
+//    then such a number passes the range test and the clip: the cone is hit at a point that has nothing to do with it.
+//    A few rays in 10^9.
+// No tree can find such cones by where they stand, but they can be found by their slope: fl(fl(tangens d_y) d_y) is
+// monotone in tangens, so the values that (nearly) cancel a given ray lie within a few bit patterns of
+// q = |d_xz|^2 / d_y^2, and the scene's distinct tangens values are kept in a table keyed by their bit patterns.
+// Layout (uint32 words):
+//   [0] n values  [1] bits of the smallest  [2] bits of the largest  [3] shift (>= 7)  [4] cells B  [7] cones kept m
 //   [5], [6] the smallest value times (1 - 2^-10) and the largest times (1 + 2^-10), as float bits
-//   [8 ..]  B cells of four words: (value, index, value, index) of the at most two values whose
-//           (bits - [1]) >> shift is the cell's number; unused entries hold PT_CONE_TAB_NONE, and a cell that would
-//           need more than two holds PT_CONE_TAB_MORE in its first word
-//   then the n values ascending (float bits) and their n list indices, for such cells.
-// Returns whether some cone's a is exactly 0 for direction d, and the largest list index of such a cone: the scan's
-// answer is then the scan's answer from that entry on (the entry is accepted whatever came before it, and with the
-// running t a NaN nothing that came before matters).  A range test on the ray alone comes first (no memory; three rays
-// in four end there on the 100k mixed objects), then one 16-byte load (two where the candidates straddle a cell boundary).
+//   [8 ..]  B cells of four words: (value, position, value, position) of the at most two values whose
+//           (bits - [1]) >> shift is the cell's number, position = the value's rank among the n; unused entries hold
+//           PT_CONE_TAB_NONE, and a cell that would need more than two holds PT_CONE_TAB_MORE in its first word
+//   then the n values ascending (float bits), the largest list index that has each, n + 1 offsets into the member
+//   array, and the m members: the list indices of the cones, grouped by value.
+// cone_table_hit() returns bit 0 when some cone's a is exactly 0 for direction d, with the largest list index of such a
+// cone (the scan's answer is then the scan's answer from that entry on: the entry is accepted whatever came before it,
+// and with the running t a NaN nothing that came before matters), and bit 1 when some cone's a is within 2^-20 of its
+// terms without being 0, with the range of positions of such values (the caller then tries those cones themselves:
+// cone_near_acceptable).  A range test on the ray alone comes first (no memory; three rays in four end there on the 100k
+// mixed objects), then one 16-byte load (two where the candidates straddle a cell boundary).
 // (A one-bit-per-16-patterns bitmap in front of the cells, its word asked for when the ray starts and looked at when the
 // traversal is over, was measured and is no faster: 100k mixed objects at 8 spp 71.5 against 70.7 ms.)
 #define PT_CONE_TAB_HEADER 8u
 #define PT_CONE_TAB_NONE 0xFFFFFFFFu
 #define PT_CONE_TAB_MORE 0xFFFFFFFEu
-#define PT_CONE_TAB_SLACK 8u // q is off by at most six bit patterns: d_y^2, the reciprocal, the product and the reference's two products round once each
-PT_DI bool cone_table_hit(const uint32_t *__restrict__ tab, v3 d, uint32_t &last_index)
+#define PT_CONE_TAB_NEAR (1.0f / 1048576.0f) // |a| up to this share of its terms counts as nearly cancelled (eight units in the last place at least)
+#define PT_CONE_TAB_SLACK 48u // q is off by at most six bit patterns (d_y^2, the reciprocal, the product and the reference's two products round once each); 2^-20 is 8 to 16 more, and their roundings 2
+PT_DI uint32_t cone_table_hit(const uint32_t *__restrict__ tab, v3 d, uint32_t &last_index, uint32_t &near_lo, uint32_t &near_hi)
 {
     const float S = d.x * d.x + d.z * d.z; // |d_xz|^2 as vlen2 of (d_x, 0, d_z) rounds it (cone.h:108, vec3.h:154-156)
     const float dy2 = d.y * d.y;
     last_index = 0;
-    if (!(S >= dy2 * __uint_as_float(tab[5]) && S <= dy2 * __uint_as_float(tab[6]))) return false; // (a NaN ends here too)
+    near_lo = 0xFFFFFFFFu;
+    near_hi = 0;
+    if (!(S >= dy2 * __uint_as_float(tab[5]) && S <= dy2 * __uint_as_float(tab[6]))) return 0u; // (a NaN ends here too)
     const uint32_t lo = tab[1], span = tab[2] - lo, shift = tab[3];
     const uint32_t key = min(max(__float_as_uint(S * __builtin_amdgcn_rcpf(dy2)), lo), tab[2]) - lo;
     const uint32_t b0 = (key > PT_CONE_TAB_SLACK ? key - PT_CONE_TAB_SLACK : 0u) >> shift, b1 = min(key + PT_CONE_TAB_SLACK, span) >> shift;
     const uint4 *cells = reinterpret_cast<const uint4 *>(tab + PT_CONE_TAB_HEADER);
-    const uint4 c0 = cells[b0];
-    bool found = false;
-    auto check = [&](uint32_t vbits, uint32_t index) { // tangens * r.d.y * r.d.y against |d_xz|^2, cone.h:108
-        if ((__uint_as_float(vbits) * d.y) * d.y == S) { // (PT_CONE_TAB_NONE is a NaN: never equal)
-            found = true;
-            last_index = max(last_index, index);
+    const uint32_t n = tab[0], nb = tab[4];
+    const float *val = reinterpret_cast<const float *>(tab + PT_CONE_TAB_HEADER + 4u * (size_t)nb);
+    const uint32_t *last = reinterpret_cast<const uint32_t *>(val + n);
+    const float tol = S * PT_CONE_TAB_NEAR;
+    uint32_t found = 0;
+    auto check = [&](float v, uint32_t pos) { // tangens * r.d.y * r.d.y against |d_xz|^2, cone.h:108
+        const float a = S - (v * d.y) * d.y; // (PT_CONE_TAB_NONE is a NaN: neither branch)
+        if (a == 0.0f) {
+            found |= 1u;
+            last_index = max(last_index, last[pos]);
+        } else if (fabsf(a) <= tol) {
+            found |= 2u;
+            near_lo = min(near_lo, pos);
+            near_hi = max(near_hi, pos + 1u);
         }
     };
-    check(c0.x, c0.y); check(c0.z, c0.w);
+    const uint4 c0 = cells[b0];
+    check(__uint_as_float(c0.x), c0.y); check(__uint_as_float(c0.z), c0.w);
     uint4 c1 = c0;
-    if (b1 != b0) { // the candidates straddle a cell boundary (b1 = b0 + 1: a cell is at least 32 bit patterns wide)
+    if (b1 != b0) { // the candidates straddle a cell boundary (b1 = b0 + 1: a cell is at least 128 bit patterns wide)
         c1 = cells[b1];
-        check(c1.x, c1.y); check(c1.z, c1.w);
+        check(__uint_as_float(c1.x), c1.y); check(__uint_as_float(c1.z), c1.w);
     }
     if (c0.x == PT_CONE_TAB_MORE || c1.x == PT_CONE_TAB_MORE) { // a crowded cell: the sorted values
-        const uint32_t n = tab[0], nb = tab[4];
-        const float *val = reinterpret_cast<const float *>(tab + PT_CONE_TAB_HEADER + 4u * (size_t)nb);
-        const uint32_t *index = reinterpret_cast<const uint32_t *>(val + n);
         uint32_t i0 = 0, i1 = n;
-        while (i0 < i1) { // the first value whose term is not below S
+        while (i0 < i1) { // the first value whose term is not more than tol below S
             const uint32_t mid = (i0 + i1) >> 1;
-            if ((val[mid] * d.y) * d.y < S) i0 = mid + 1u;
+            if (S - (val[mid] * d.y) * d.y > tol) i0 = mid + 1u;
             else i1 = mid;
         }
-        for (; i0 < n && (val[i0] * d.y) * d.y == S; ++i0) {
-            found = true;
-            last_index = max(last_index, index[i0]);
-        }
+        for (; i0 < n && S - (val[i0] * d.y) * d.y >= -tol; ++i0) check(val[i0], i0);
     }
     return found;
 }
 
-// After the tree walk of a scene with cones: the list entry the scan has to start at for this ray (and need_exact set)
-// when some cone's leading coefficient is exactly 0 for it, else 0 and need_exact as it was.
-template <int KIND>
-PT_DI uint32_t cone_scan_from(const SceneDev &sc, const Ray &r, bool &need_exact)
+// Whether the reference's cone test (cone.h:101-129) can accept one of the cones of the table's values [near_lo, near_hi)
+// for this ray at all, under any running t: a cone that cannot is the tree's to ignore, one that can sends the ray to the
+// list scan.  Cones whose a is exactly 0 are skipped (they are the other case of cone_table_hit).
+static __device__ __attribute__((noinline)) bool cone_near_acceptable(const uint32_t *__restrict__ tab, const PrimRec *__restrict__ list, float ox, float oy, float oz, float dx,
+                                                                      float dy, float dz, float t_min, float t_max, uint32_t near_lo, uint32_t near_hi)
 {
-    uint32_t from = 0;
-    if (KIND == PT_KIND_ANY && sc.cone_tab && cone_table_hit(sc.cone_tab, r.d, from)) need_exact = true;
-    else from = 0;
-    return from;
+    Ray r;
+    r.o = V(ox, oy, oz);
+    r.d = V(dx, dy, dz);
+    const uint32_t n = tab[0], nb = tab[4];
+    const uint32_t *first = tab + PT_CONE_TAB_HEADER + 4u * (size_t)nb + 2u * (size_t)n, *member = first + n + 1u;
+    for (uint32_t j = first[near_lo]; j < first[near_hi]; ++j) {
+        const PrimRec q = list[member[j]];
+        ConeRoots cr;
+        if (!cone_roots(q, r, cr) || cr.a == 0.0f) continue;
+        if ((!(cr.r1 < t_min || t_max < cr.r1) && cone_clip_ok(cr, cr.r1)) || (!(cr.r2 < t_min || t_max < cr.r2) && cone_clip_ok(cr, cr.r2))) return true;
+    }
+    return false;
+}
+
+// After the tree walk of a scene with cones: need_exact set and the list entry the scan has to start at, for a ray with
+// a cone whose leading coefficient is exactly 0 (from that cone on) or nearly so and acceptable (from the start; with
+// both, from the cone on: the scan itself then meets the other); else 0 and need_exact as it was.
+template <int KIND>
+PT_DI uint32_t cone_scan_from(const SceneDev &sc, const Ray &r, float t_min, float t_max, bool &need_exact)
+{
+    if (KIND != PT_KIND_ANY || !sc.cone_tab) return 0;
+    uint32_t from = 0, near_lo, near_hi;
+    const uint32_t found = cone_table_hit(sc.cone_tab, r.d, from, near_lo, near_hi);
+    if (!found) return 0;
+    if ((found & 2u) && !cone_near_acceptable(sc.cone_tab, sc.prims_list, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max, near_lo, near_hi) && !(found & 1u)) return 0;
+    need_exact = true;
+    return (found & 1u) ? from : 0u;
 }
 
 // The reference's hit arithmetic is fp32 on unnormalised rays, and what it ACCEPTS is not exactly the

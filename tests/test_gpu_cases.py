@@ -554,8 +554,11 @@ def test_large_scene_render_crop(ctx, which):
     got, st = ctx.render(3840, 2160, 1, 50)
     ref, _ = osc.render(3840, 2160, 1, 50, region=(x0, y0, w, h))
     frac, rmse = _image_close(got[y0:y0 + h, x0:x0 + w], ref)
-    assert frac <= 0.015 and rmse < 5e-3, (which, frac, rmse)
-    assert np.isfinite(got).all() and st["exact_fallbacks"] == 0 and st["rays"] > st["primary_rays"]
+    print(which, "crop: fraction of pixels beyond 2e-5", frac, "relative RMSE", rmse, "list scans", st["exact_fallbacks"], "of", st["rays"], "rays")
+    assert frac == 0 and rmse < 1e-5, (which, frac, rmse)
+    # the list scan answers next to nothing: on the mixed objects the few rays for which a cone's nearly cancelled quadratic
+    # yields an acceptable root (a few in 10^8), on the spheres none
+    assert np.isfinite(got).all() and st["exact_fallbacks"] <= (1e-6 * st["rays"] if which == "mixed_100k" else 0) and st["rays"] > st["primary_rays"]
 
 
 @pytest.mark.parametrize("n", [30_000, 1_000_000])
@@ -661,6 +664,40 @@ def test_cone_whose_leading_coefficient_cancels(ctx, where):
         assert not bad[:m].any(), (mode, int(bad[:m].sum()))
         assert not (bad[m:] & (want["nan_flag"][m:] == 0)).any(), mode
         assert mode == api.TRACE_LINEAR or (got["flags"][:m] & 1).all()  # answered by the list, from that entry on
+
+
+def test_cone_whose_leading_coefficient_all_but_cancels(ctx):
+    """The neighbour of the case above: direction (0.59999996, 1, 0) against a cone of tangens 0.36 gives
+    a = |d_xz|^2 - tangens d_y^2 = -2 units in the last place of its terms.  The roots are then the rounding noise of
+    -half_b -+ sqrtd over that -- 32, 64 -- and for a few origins in 10^5 such a number passes the range test and the clip
+    (cone.h:116-123): the cone is hit at a point tens of units away from it, outside any box a tree could give it.  The
+    rays are found with the oracle on the cone alone (hits farther than 5 units from a cone of height 1), then traced
+    through a scene of 400 objects with the cone in the middle of the list: oracle, list scan and tree walk must agree."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    lone = scenes.SceneBuilder()
+    lone.cone((0.0, 0.0, 0.0), 1.0, 0.6, lone.lambertian((0.5, 0.5, 0.5)))
+    lone.camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 5.0)
+    m = 2000000
+    o = ((rng.random((m, 3)) - 0.5) * 200.0).astype(np.float32)
+    d = np.tile(np.array([[0.59999996, 1.0, 0.0]], dtype=np.float32), (m, 1)) * rng.choice([-1.0, 1.0], (m, 1)).astype(np.float32)
+    h = util.oracle_scene(lone).trace(o, d)
+    far = (h["prim"] == 0) & (np.linalg.norm(h["p"], axis=1) > 5.0)
+    assert far.sum() >= 10, int(far.sum())
+    o, d = np.ascontiguousarray(o[far]), np.ascontiguousarray(d[far])
+    n = 400
+    src = scenes.mixed_scene(n=n, extent=20.0, seed=3)
+    a = {k: v.copy() for k, v in src.arrays().items()}
+    a["prim_param"][:, :3] += np.float32(500.0)  # out of the way of these rays (rect parameters are shifted too; any scene will do)
+    a["prim_type"][n // 2] = api.CONE
+    a["prim_param"][n // 2] = [0.0, 0.0, 0.0, 1.0, 0.6, np.float32(0.6) * np.float32(0.6)]
+    b = scenes.ArrayScene(a, src.background, src.camera_args)
+    want = util.oracle_scene(b).trace(o, d)
+    assert (want["prim"] == n // 2).sum() >= 10 and (np.linalg.norm(want["p"][want["prim"] == n // 2], axis=1) > 5.0).all()
+    ctx.upload(b.desc())
+    for mode in (api.TRACE_LINEAR, api.TRACE_BVH, api.TRACE_BVH_IN_SCENE):
+        got = ctx.trace(o, d, mode=mode)
+        bad = util.hits_equal(got, want, nan_equal=True)
+        assert not bad.any(), (mode, int(bad.sum()))
 
 
 @pytest.mark.parametrize("n", [300, 3000])
