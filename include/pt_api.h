@@ -107,7 +107,8 @@ typedef struct pt_stats {
     uint64_t primary_rays;
     uint64_t box_tests, prim_tests; /* only with PT_RENDER_COUNT_TESTS */
     uint64_t exact_fallbacks;       /* rays resolved by a list-order scan of the objects: a hit at t = NaN, a non-finite ray, more than 16
-                                       candidate objects, or (scenes traversed from on-chip memory) a cone whose quadratic's leading
+                                       candidate objects, a cone whose quadratic's leading coefficient has all but cancelled and whose
+                                       roots pass its tests all the same, or (scenes traversed from on-chip memory) one whose
                                        coefficient is exactly 0 for the ray, cone.h:108 */
     double ms_total;                /* device time of the whole call (events on the call's stream) */
     double ms_raygen, ms_intersect, ms_shade, ms_film; /* only with PT_RENDER_STAGE_TIMES | PT_RENDER_SPLIT_KERNELS */
