@@ -1,7 +1,7 @@
 """Fuzz: renders of random small scenes, every pipeline of the library against the CPU oracle.
 
 Scenes of 1 to 20 000 objects of every kind with random materials (all four classes, lights included), sizes and
-positions, a random camera (aperture included), 24 x 16 pixels, 4 samples, depth 50.  For every scene: the default
+positions (three in ten far from the origin), a random camera (aperture included; three in ten far from the scene), 24 x 16 pixels, 4 samples, depth 50.  For every scene: the default
 pipeline against the oracle (every pixel within 2e-5, equal ray counts) and the other pipelines against the default one
 (bit-identical, equal ray counts).  Prints one line per scene; exit status 1 when anything differs.
 
@@ -35,8 +35,9 @@ def random_scene(rng):
         else:
             mats.append(b.diffuse_light(c * 8.0))
     size = spread * 10.0 ** rng.uniform(-1.5, -0.5)
+    centre = rng.standard_normal(3) * 10.0 ** rng.uniform(1.0, 3.5) if rng.random() < 0.3 else np.zeros(3)  # a scene far from the origin
     for _ in range(n):
-        c = (rng.random(3) - 0.5) * spread
+        c = centre + (rng.random(3) - 0.5) * spread
         r = size * (0.3 + rng.random())
         m = mats[int(rng.integers(0, len(mats)))]
         what = int(rng.integers(0, 6))
@@ -53,10 +54,11 @@ def random_scene(rng):
         else:
             b.cone(tuple(c), r * 10.0 ** rng.uniform(-0.7, 0.7), r, m)
     if rng.random() < 0.5:  # a ground sphere
-        b.sphere((0.0, -spread * 50.0 - spread * 0.5, 0.0), spread * 50.0, mats[0])
+        b.sphere(tuple(centre + [0.0, -spread * 50.0 - spread * 0.5, 0.0]), spread * 50.0, mats[0])
     eye = rng.standard_normal(3)
-    eye *= spread * rng.uniform(0.8, 2.0) / np.linalg.norm(eye)
-    b.camera(tuple(eye), tuple((rng.random(3) - 0.5) * spread * 0.3), (0, 1, 0), float(rng.uniform(20, 70)), 1.5,
+    far = 10.0 ** rng.uniform(0.5, 1.8) if rng.random() < 0.3 else 1.0  # a camera far from the scene, with a lens to match
+    eye *= far * spread * rng.uniform(0.8, 2.0) / np.linalg.norm(eye)
+    b.camera(tuple(centre + eye), tuple(centre + (rng.random(3) - 0.5) * spread * 0.3), (0, 1, 0), float(rng.uniform(20, 70) / far), 1.5,
              float(rng.choice([0.0, 0.05 * spread])), float(np.linalg.norm(eye)))
     return b, n
 
