@@ -3,6 +3,7 @@
 // linear hittable_list scan (hittable_list.h:92-98).  This builder is what turns those volumes
 // into the flattened tree the gfx950 traversal kernel walks.
 #include "pt_bvh.h"
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -434,6 +435,60 @@ struct WideMaker {
 };
 
 } // namespace
+
+namespace {
+struct Wide32Maker {
+    const BvhBuild &bvh;
+    std::vector<float> &out;
+    uint32_t max_depth = 0;
+    int32_t emit(int32_t node, uint32_t depth)
+    {
+        max_depth = std::max(max_depth, depth);
+        auto children_of = [&](int32_t nd, std::vector<WideChild> &list) {
+            const HostNode &n = bvh.nodes[(size_t)nd];
+            for (int c = 0; c < 2; ++c) {
+                if (!(n.b[0][c] < kInf)) continue; // absent
+                WideChild k;
+                for (int a = 0; a < 3; ++a) { k.box.lo[a] = n.b[a][c]; k.box.hi[a] = n.b[a][2 + c]; }
+                k.ref = n.c[c];
+                list.push_back(k);
+            }
+        };
+        std::vector<WideChild> kids;
+        children_of(node, kids);
+        while (kids.size() < 4) { // pull up the inner child with the largest surface
+            int pick = -1;
+            double best = -1.0;
+            for (size_t k = 0; k < kids.size(); ++k)
+                if (kids[k].ref >= 0 && WideMaker::area(kids[k].box) > best) { best = WideMaker::area(kids[k].box); pick = (int)k; }
+            if (pick < 0) break;
+            const int32_t inner = kids[(size_t)pick].ref;
+            kids.erase(kids.begin() + pick);
+            children_of(inner, kids);
+        }
+        const size_t me = out.size() / 28;
+        out.resize(out.size() + 28, kInf);
+        int32_t refs[4] = {kWideAbsent, kWideAbsent, kWideAbsent, kWideAbsent};
+        for (size_t k = 0; k < kids.size(); ++k) {
+            for (int a = 0; a < 3; ++a) {
+                out[me * 28 + (size_t)a * 8 + k] = kids[k].box.lo[a];
+                out[me * 28 + (size_t)a * 8 + 4 + k] = kids[k].box.hi[a];
+            }
+        }
+        for (size_t k = 0; k < kids.size(); ++k) refs[k] = kids[k].ref >= 0 ? emit(kids[k].ref, depth + 1) : kids[k].ref;
+        memcpy(&out[me * 28 + 24], refs, 16);
+        return (int32_t)me;
+    }
+};
+} // namespace
+
+uint32_t make_wide_fp32(const BvhBuild &bvh, std::vector<float> &out)
+{
+    out.clear();
+    Wide32Maker m{bvh, out};
+    m.emit(0, 1);
+    return m.max_depth;
+}
 
 void make_wide(const BvhBuild &bvh, WideBuild &out)
 {

@@ -92,6 +92,11 @@ struct WideBuild {
 // The four-wide form of a binary tree (after a build or a refit).  O(N).
 void make_wide(const BvhBuild &bvh, WideBuild &out);
 
+// Experiment (-DPT_LDS_WIDE4): the four-wide form with unquantised planes, for scenes traversed from LDS.  A node is
+// seven quads of floats: (lo of the four children) and (hi ...) per axis, then the four references (bit patterns);
+// an absent child has lo = hi = +inf.  Returns the nodes on the longest root-to-leaf path.
+uint32_t make_wide_fp32(const BvhBuild &bvh, std::vector<float> &out);
+
 // Binned SAH (16 bins per axis), leaves of at most leaf_max objects.  Returns "" or an error text.
 std::string build_bvh(const pt_scene_desc &desc, uint32_t leaf_max, BvhBuild &out);
 

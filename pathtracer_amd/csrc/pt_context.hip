@@ -427,8 +427,19 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     // node fetches per ray, 1M spheres 2.82 -> 3.47 Grays/s; with cones (whose kernel variant waits on those fetches
     // with four waves per SIMD) 100k mixed objects 4.54 -> 5.02.  pt_tuning.wide_nodes overrides.
     pt::WideBuild wb;
+#ifdef PT_LDS_WIDE4
+    // experiment: scenes of spheres small enough for LDS get four-wide unquantised nodes there (in the `wide` buffer)
+    std::vector<float> w32;
+    uint32_t w32_depth = 0;
+    const bool want_w32 = only_spheres && nb + pb <= 48 * 1024 && b.nodes.size() > 1;
+    if (want_w32) w32_depth = pt::make_wide_fp32(b, w32);
+    const bool want_wide = want_w32 || (nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, 1) != 0);
+    if (want_wide && !want_w32) pt::make_wide(b, wb);
+    if (want_w32) wb.nodes.resize((w32.size() * 4 + sizeof(pt::WideNode) - 1) / sizeof(pt::WideNode)); // (sized in WideNodes for the upload below)
+#else
     const bool want_wide = nb + pb > 48 * 1024 && tuned(ctx->tune.wide_nodes, 1) != 0;
     if (want_wide) pt::make_wide(b, wb);
+#endif
 
     const std::vector<uint32_t> cone_tab = make_cone_table(list);
     BvhNode *n_nodes = nullptr;
@@ -451,6 +462,12 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
         if ((e = hipMemcpy(n_prims, leaf.data(), pb, hipMemcpyHostToDevice)) != hipSuccess) return e;
         if ((e = hipMemcpy(n_list, list.data(), pb, hipMemcpyHostToDevice)) != hipSuccess) return e;
         if ((e = hipMemcpy(n_mats, mats.data(), mb, hipMemcpyHostToDevice)) != hipSuccess) return e;
+#ifdef PT_LDS_WIDE4
+        if (want_w32) {
+            if ((e = hipMemcpy(n_wide, w32.data(), w32.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return e;
+            return hipSuccess;
+        }
+#endif
         if (want_wide && (e = hipMemcpy(n_wide, wb.nodes.data(), wb.nodes.size() * sizeof(pt::WideNode), hipMemcpyHostToDevice)) != hipSuccess) return e;
         return hipSuccess;
     };
@@ -479,6 +496,15 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     sc.n_prims = desc->n_prims;
     sc.n_nodes = (uint32_t)b.nodes.size();
     sc.stack_cap = std::max(8u, b.max_depth + 2); // one entry per level of a descent, and the "done" entry at the bottom
+#ifdef PT_LDS_WIDE4
+    sc.n_wide4 = want_w32 ? (uint32_t)(w32.size() / 28) : 0u;
+    if (want_w32) {
+        sc.stack_cap = std::max(8u, 3u * w32_depth + 2u);
+        sc.wide_stack_cap = 0;
+        ctx->wide_depth = 0;
+        ctx->n_wide_alloc = 0;
+    }
+#endif
     // a scene that is one leaf (at most eight objects): k_paths' FLAT kernels start at the leaf, without the visit to a root whose one box every ray is in
     sc.root_ref = b.nodes.size() == 1 && b.nodes[0].c[0] < 0 && !(b.nodes[0].b[0][1] < INFINITY) ? b.nodes[0].c[0] : 0;
     sc.cone = b.cone;
@@ -540,7 +566,12 @@ static uint32_t grid_for(const pt_context *ctx, size_t n)
 static size_t lds_scene_bytes(const pt_context *ctx)
 {
     const SceneDev &sc = ctx->sc;
+#ifdef PT_LDS_WIDE4
+    if (ctx->kind != PT_KIND_SPHERES || (sc.n_wide4 == 0 && sc.root_ref == 0)) return 0; // the experiment's LDS kernels hold four-wide nodes: spheres only
+    size_t b = lds_scene_size(sc.n_wide4, sc.n_prims) + (size_t)sc.stack_cap * PT_ISECT_LDS_BLOCK * 4;
+#else
     size_t b = lds_scene_size(sc.n_nodes, sc.n_prims) + (size_t)sc.stack_cap * PT_ISECT_LDS_BLOCK * 4;
+#endif
     return b <= 80 * 1024 ? b : 0; // two workgroups per CU must fit in 160 KB
 }
 
@@ -693,7 +724,11 @@ static PathsShape paths_shape(pt_context *ctx, uint32_t flags, bool count, bool 
     PathsShape ps;
     const bool want_lds = (flags & PT_RENDER_NO_LDS_SCENE) == 0 && tuned(tu.lds_scene, 1) != 0;
     ps.sort = !force_stream && (flags & PT_RENDER_NO_SORT) == 0 && tuned(tu.sort_by_material, 0) != 0; // measured slower on the spheres scene: opt-in
+#ifdef PT_LDS_WIDE4
+    const size_t scene_bytes = lds_scene_size(sc.n_wide4, sc.n_prims);
+#else
     const size_t scene_bytes = lds_scene_size(sc.n_nodes, sc.n_prims);
+#endif
     int block = tuned(tu.block, 0);
     if (block != 256 && block != 512) {
         // LDS-resident scenes: 512 (one scene copy per 8 waves).  Scenes traversed from HBM: 256 measured best without cones;
@@ -710,12 +745,18 @@ static PathsShape paths_shape(pt_context *ctx, uint32_t flags, bool count, bool 
     ps.block = block;
     const size_t stack_bytes = (size_t)sc.stack_cap * block * 4;
     ps.lds = want_lds && !force_stream && scene_bytes + stack_bytes <= 64 * 1024;
+#ifdef PT_LDS_WIDE4
+    ps.lds = ps.lds && ctx->kind == PT_KIND_SPHERES && (sc.n_wide4 != 0 || sc.root_ref != 0); // the experiment's LDS kernels: spheres only
+#endif
     ps.lds_bytes = stack_bytes + (ps.lds ? scene_bytes : 0);
     // scenes traversed from HBM take the streaming kernel (pt_tuning.pipeline overrides)
     const int pipeline = tuned(tu.pipeline, ps.lds ? PT_DEFAULT_LDS_PIPELINE : 1);
     ps.ring = !force_stream && !ps.sort && ps.lds && pipeline == 2; // (scenes that do not fit LDS: the streaming kernel instead)
     ps.stream = force_stream || (!ps.sort && pipeline != 0 && !ps.ring);
     ps.wide = ps.stream && sc.wide != nullptr;
+#ifdef PT_LDS_WIDE4
+    if (sc.n_wide4) ps.wide = false; // (`wide` holds the unquantised nodes of the LDS kernels)
+#endif
     // the wide traversal's stack; the exact replay of cone scenes walks the binary tree on the same stack
     ps.stream_stack_bytes = ps.wide ? (size_t)std::max(sc.wide_stack_cap, ctx->has_cones ? sc.stack_cap : 0u) * block * 4 : stack_bytes;
     int per_cu = tuned(tu.workgroups_per_cu, 0);

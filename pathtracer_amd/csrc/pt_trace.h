@@ -31,6 +31,9 @@ struct SceneDev {
     int32_t root_ref;   // the reference of the scene's only leaf where the tree is one (at most eight objects: the FLAT kernels start there), else 0
     const float4 *wide;      // the four-wide quantised form of the tree (pt::WideNode, 64 B each), for scenes traversed from HBM; or null
     uint32_t wide_stack_cap; // stack entries its traversal may use
+#ifdef PT_LDS_WIDE4
+    uint32_t n_wide4; // experiment: four-wide unquantised nodes (in `wide`) for the LDS-resident kernels
+#endif
     const uint32_t *cone_tab; // the cones' distinct slopes, for cone_table_hit(); null for a scene without cones
     pt::ConeParams cone; // how wide a cone the slab test gives a ray
     DeviceCamera cam;
@@ -418,6 +421,7 @@ PT_DI void planes_of_record(const float4 &a, const float4 &b, const float4 &c, c
 
 struct GlobalSrc {
     static constexpr bool in_lds = false;
+    static constexpr bool wide4 = false;
     const BvhNode *nodes;
     const PrimRec *prims;
     pt::ConeParams cone;
@@ -442,8 +446,46 @@ struct GlobalSrc {
 // per-ray offset) serves both reads, four address instructions per visit instead of thirteen; and the 80-byte stride
 // spreads the lanes of a read over all sixteen 16-byte bank slots, which a 64-byte stride would not.
 #define PT_LDS_NODE_BYTES 80u
+#ifdef PT_LDS_WIDE4
+// Experiment: four-wide nodes with unquantised planes in LDS.  A node is seven quads (112 bytes: the stride spreads the
+// lanes of a read over all sixteen 16-byte bank slots): per axis (lo of the four children, hi of the four children), then the
+// references.  The quad a ray meets first on an axis is at byte 0 or 16 of the axis' pair by the sign of its direction.
 struct LdsSrc {
     static constexpr bool in_lds = true;
+    static constexpr bool wide4 = true;
+    const char *nodes;
+    const float4 *prims;
+    uint32_t n_nodes, n_prims;
+    pt::ConeParams cone;
+    static __device__ __forceinline__ void adapt(BoxRay &br)
+    {
+        br.sx = br.sx ? 16u : 0u;
+        br.sy = 32u + (br.sy ? 16u : 0u);
+        br.sz = 64u + (br.sz ? 16u : 0u);
+    }
+    __device__ __forceinline__ void quads(int32_t i, const BoxRay &br, float4 &nx, float4 &ny, float4 &nz, float4 &fx, float4 &fy, float4 &fz, int4 &c) const
+    {
+        const char *base = nodes + (uint32_t)i * 112u;
+        nx = *reinterpret_cast<const float4 *>(base + br.sx); fx = *reinterpret_cast<const float4 *>(base + (br.sx ^ 16u));
+        ny = *reinterpret_cast<const float4 *>(base + br.sy); fy = *reinterpret_cast<const float4 *>(base + (br.sy ^ 16u));
+        nz = *reinterpret_cast<const float4 *>(base + br.sz); fz = *reinterpret_cast<const float4 *>(base + (br.sz ^ 16u));
+        c = *reinterpret_cast<const int4 *>(base + 96);
+    }
+    // (the two-wide interface, for code that is compiled but never runs with this source: scenes with cones stay out of LDS in this build)
+    __device__ __forceinline__ void planes(int32_t, const BoxRay &, float2 &nx, float2 &ny, float2 &nz, float2 &fx, float2 &fy, float2 &fz, int32_t &c0, int32_t &c1) const
+    {
+        nx = ny = nz = fx = fy = fz = make_float2(3.0e38f, 3.0e38f);
+        c0 = c1 = -1;
+    }
+    __device__ __forceinline__ void prim(uint32_t slot, float4 &w0, float4 &w1) const
+    {
+        w0 = prims[slot]; w1 = prims[n_prims + slot];
+    }
+};
+#else
+struct LdsSrc {
+    static constexpr bool in_lds = true;
+    static constexpr bool wide4 = false;
     const char *nodes;   // n_nodes records of PT_LDS_NODE_BYTES
     const float4 *prims; // 2 planes of n_prims
     uint32_t n_nodes, n_prims;
@@ -472,6 +514,7 @@ struct LdsSrc {
         w0 = prims[slot]; w1 = prims[n_prims + slot];
     }
 };
+#endif
 
 // Copies the scene into the workgroup's LDS (nodes in the 80-byte form, objects as two planes of quads) and returns
 // the first byte after it.  The caller synchronises the workgroup before traversing.
@@ -479,8 +522,13 @@ template <int BLOCK>
 PT_DI char *lds_scene_copy(const SceneDev &sc, float4 *s_mem, LdsSrc &lsrc)
 {
     char *s_nodes = reinterpret_cast<char *>(s_mem);
+    const float4 *gp = reinterpret_cast<const float4 *>(sc.prims);
+#ifdef PT_LDS_WIDE4
+    float4 *s_prims = s_mem + 7u * sc.n_wide4;
+    for (uint32_t i = threadIdx.x; i < 7u * sc.n_wide4; i += BLOCK) s_mem[i] = sc.wide[i];
+#else
     float4 *s_prims = reinterpret_cast<float4 *>(s_nodes + ((sc.n_nodes * PT_LDS_NODE_BYTES + 15u) & ~15u));
-    const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes), *gp = reinterpret_cast<const float4 *>(sc.prims);
+    const float4 *gn = reinterpret_cast<const float4 *>(sc.nodes);
     for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes; i += BLOCK) {
         const float4 q = gn[i]; // quarter i & 3 of node i >> 2: an axis quad (lo0, lo1, hi0, hi1), or the references
         float2 *dst = reinterpret_cast<float2 *>(s_nodes + (i >> 2) * PT_LDS_NODE_BYTES + (i & 3u) * 24u);
@@ -492,14 +540,19 @@ PT_DI char *lds_scene_copy(const SceneDev &sc, float4 *s_mem, LdsSrc &lsrc)
             dst[2] = make_float2(q.z, q.w);
         }
     }
+#endif
     for (uint32_t i = threadIdx.x; i < 2 * sc.n_prims; i += BLOCK) s_prims[(i & 1u) * sc.n_prims + (i >> 1)] = gp[i];
     lsrc.nodes = s_nodes;
     lsrc.prims = s_prims;
     return reinterpret_cast<char *>(s_prims + 2 * sc.n_prims);
 }
-static size_t lds_scene_size(uint32_t n_nodes, uint32_t n_prims)
+static size_t lds_scene_size(uint32_t n_nodes /* PT_LDS_WIDE4: four-wide ones */, uint32_t n_prims)
 {
+#ifdef PT_LDS_WIDE4
+    return (size_t)n_nodes * 112u + (size_t)n_prims * 32;
+#else
     return (((size_t)n_nodes * PT_LDS_NODE_BYTES + 15u) & ~(size_t)15u) + (size_t)n_prims * 32;
+#endif
 }
 
 #define PT_SCAN_MAX 16 // candidates the exact replay keeps per ray
@@ -814,7 +867,46 @@ PT_DI HitResult bvh_nearest(const Src &src, uint32_t stack_cap, const Ray &r, fl
     for (;;) {
         // Descend until this lane holds a leaf (or has nothing left); lanes that found theirs wait here, so
         // that the expensive object tests below run with as many lanes of the wave as possible.
-        while (!FLAT && cur >= 0) {
+#ifdef PT_LDS_WIDE4
+        if constexpr (Src::wide4 && !FLAT) {
+        while (cur >= 0) { // experiment: four children per visit, nearest first
+            float4 qnx, qny, qnz, qfx, qfy, qfz;
+            int4 qc;
+            src.quads(cur, br, qnx, qny, qnz, qfx, qfy, qfz, qc);
+            const float nxs[4] = {qnx.x, qnx.y, qnx.z, qnx.w}, nys[4] = {qny.x, qny.y, qny.z, qny.w}, nzs[4] = {qnz.x, qnz.y, qnz.z, qnz.w};
+            const float fxs[4] = {qfx.x, qfx.y, qfx.z, qfx.w}, fys[4] = {qfy.x, qfy.y, qfy.z, qfy.w}, fzs[4] = {qfz.x, qfz.y, qfz.z, qfz.w};
+            int32_t cr[4] = {qc.x, qc.y, qc.z, qc.w};
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float nx = __builtin_fmaf(nxs[k], br.anx, br.cnx), ny = __builtin_fmaf(nys[k], br.any, br.cny), nz = __builtin_fmaf(nzs[k], br.anz, br.cnz);
+                const float fx = __builtin_fmaf(fxs[k], br.afx, br.cfx), fy = __builtin_fmaf(fys[k], br.afy, br.cfy), fz = __builtin_fmaf(fzs[k], br.afz, br.cfz);
+                float m, tn, tf;
+                asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(nz), "v"(t_min));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(m));
+                asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(fz), "v"(best_t));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(m));
+                const bool hit = tn <= tf + br.eps && cr[k] != pt::kWideAbsent;
+                key[k] = ((__float_as_uint(tn) & ~3u) | (uint32_t)k) | (hit ? 0u : 0xFFFFFFFFu); // tn >= t_min > 0: its bits order as it does
+            }
+            if (COUNT) n_box += 4;
+            auto order2 = [](uint32_t &a, uint32_t &b, int32_t &ra, int32_t &rb) {
+                const bool s = b < a;
+                const uint32_t lo = s ? b : a, hi = s ? a : b;
+                const int32_t rlo = s ? rb : ra, rhi = s ? ra : rb;
+                a = lo; b = hi; ra = rlo; rb = rhi;
+            };
+            order2(key[0], key[1], cr[0], cr[1]); order2(key[2], key[3], cr[2], cr[3]); order2(key[0], key[2], cr[0], cr[2]);
+            order2(key[1], key[3], cr[1], cr[3]); order2(key[1], key[2], cr[1], cr[2]);
+            if (key[3] != 0xFFFFFFFFu) stack[(sp++) * STRIDE] = (uint32_t)cr[3];
+            if (key[2] != 0xFFFFFFFFu) stack[(sp++) * STRIDE] = (uint32_t)cr[2];
+            if (key[1] != 0xFFFFFFFFu) stack[(sp++) * STRIDE] = (uint32_t)cr[1];
+            cur = cr[0];
+            if (key[0] == 0xFFFFFFFFu) cur = (int32_t)stack[(--sp) * STRIDE];
+        }
+        }
+#endif
+        while (!FLAT && !Src::wide4 && cur >= 0) {
             float2 nx, ny, nz, fx, fy, fz;
             int32_t c0, c1;
             src.planes(cur, br, nx, ny, nz, fx, fy, fz, c0, c1);

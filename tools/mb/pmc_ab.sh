@@ -11,7 +11,7 @@ import csv, glob, sys, collections
 f = glob.glob('/tmp/pmcab/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if r['Kernel_Name'].startswith('void k_paths<false') or r['Kernel_Name'].startswith('void k_paths_stream<false'):
+    if r['Kernel_Name'].startswith(('void k_paths<false', 'void k_paths_stream<false', 'void k_paths_ring<false')):
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 print(sys.argv[1], {k: round(sum(v) / len(v) / 1e6, 1) for k, v in sorted(acc.items())})
 PY
