@@ -741,6 +741,41 @@ def test_render_through_a_cancelling_cone(ctx, n):
         assert st["exact_fallbacks"] + st["exact_replays"] >= w * h * spp, tune  # every primary ray went the special way
 
 
+def test_random_scenes_tree_equals_scan(ctx):
+    """A short run of tools/mb/fuzz_trace.py's generator: scenes of random size, mix, scale and distance from the origin,
+    rays between random points, aimed from afar, grazing, and three generations off the hit points; the tree walk
+    (both ray cones) must return the list scan's record for every ray.  (The long runs are in the design notes.)"""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mb", "fuzz_trace.py")
+    spec = importlib.util.spec_from_file_location("fuzz_trace", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    rays = 0
+    for _ in range(24):
+        b, pos, info = fz.random_scene(rng)
+        ctx.upload(b.desc())
+        o, d = fz.rays_for(pos, info[2], info[5], 90000, rng)
+        box_lo = (pos.min(0) - 0.5 * info[4]).astype(np.float32)
+        box_hi = (pos.max(0) + 0.5 * info[4]).astype(np.float32)
+        for gen in range(3):
+            scan = ctx.trace(o, d, mode=api.TRACE_LINEAR)
+            assert not fz.differing(ctx.trace(o, d), scan).any(), (info, gen)
+            inside = ((o >= box_lo) & (o <= box_hi)).all(axis=1)
+            assert not (fz.differing(ctx.trace(o, d, mode=api.TRACE_BVH_IN_SCENE), scan) & inside).any(), (info, gen)
+            rays += len(o)
+            hit = scan["prim"] != api.NO_PRIM
+            if hit.sum() < 100:
+                break
+            r = rng.standard_normal((int(hit.sum()), 3))
+            r /= np.linalg.norm(r, axis=1, keepdims=True)
+            o = np.ascontiguousarray(scan["p"][hit], dtype=np.float32)
+            d = np.ascontiguousarray(scan["n"][hit] + r, dtype=np.float32)
+    assert rays > 2000000
+
+
 def test_mixed_objects_tree_equals_scan_on_every_ray(ctx):
     """The 100k mixed objects (25 000 cones of as many slopes): one scattered ray in 16 000 has a direction for which some
     cone's leading coefficient cancels exactly, wherever that cone stands.  The tree walk must return the list scan's
