@@ -776,6 +776,35 @@ def test_random_scenes_tree_equals_scan(ctx):
     assert rays > 2000000
 
 
+def test_random_scenes_render_like_the_oracle(ctx):
+    """A short run of tests/studies/fuzz_render.py's generator: random scenes of 1 to 20 000 objects of every kind, all
+    four material classes, random cameras (some far away, some scenes far from the origin), 24 x 16 pixels x 4 spp at depth
+    50.  The default pipeline against the oracle (every pixel within 2e-5, equal ray counts), the others against it."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "studies", "fuzz_render.py")
+    spec = importlib.util.spec_from_file_location("fuzz_render", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.Generator(np.random.PCG64(77))
+    w, h, spp, depth = 24, 16, 4, 50
+    kernels = set()
+    for _ in range(120):
+        b, n = fz.random_scene(rng)
+        ref, rays = util.oracle_scene(b).render(w, h, spp, depth)
+        ctx.upload(b.desc())
+        got, st = ctx.render(w, h, spp, depth)
+        kernels.add(st["kernel"])
+        frac, _ = _image_close(got, ref)
+        assert frac == 0 and st["rays"] == rays, (n, st["kernel"], frac, st["rays"], rays)
+        for tune, flags in (({"pipeline": 0}, 0), ({"pipeline": 1}, 0), ({}, api.RENDER_SPLIT_KERNELS)):
+            with ctx.tuned(**tune):
+                other, so = ctx.render(w, h, spp, depth, flags=flags)
+            assert so["rays"] == rays and np.array_equal(np.nan_to_num(other, nan=-1.0), np.nan_to_num(got, nan=-1.0)), (n, tune, flags)
+    assert {2, 4} <= kernels  # both default kernels were exercised
+
+
 def test_mixed_objects_tree_equals_scan_on_every_ray(ctx):
     """The 100k mixed objects (25 000 cones of as many slopes): one scattered ray in 16 000 has a direction for which some
     cone's leading coefficient cancels exactly, wherever that cone stands.  The tree walk must return the list scan's
