@@ -485,6 +485,11 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     SceneDev &sc = ctx->sc;
     sc.wide = n_wide;
     sc.cone_tab = n_cone_tab;
+    sc.cone_hdr = ConeTabHeader{};
+    if (!cone_tab.empty()) {
+        sc.cone_hdr.n = cone_tab[0]; sc.cone_hdr.lo = cone_tab[1]; sc.cone_hdr.hi = cone_tab[2]; sc.cone_hdr.shift = cone_tab[3]; sc.cone_hdr.nb = cone_tab[4];
+        memcpy(&sc.cone_hdr.flo, &cone_tab[5], 4); memcpy(&sc.cone_hdr.fhi, &cone_tab[6], 4);
+    }
     // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
     // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
     sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 2u) : 0u; // (with the bottom entry; 31 x 256 lanes x 4 B lets five workgroups share a CU's LDS)

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     // Or some cone's coefficient has all but cancelled and its roots, which are rounding noise, pass its tests:
                     // then the list itself answers (from the start, or from the cone of the first case on).
                     uint32_t near_lo = 0, near_hi = 0;
-                    const uint32_t found = CONES && sc.cone_tab ? cone_table_hit(sc.cone_tab, r.d, scan_from, near_lo, near_hi) : 0u;
+                    const uint32_t found = CONES && sc.cone_tab ? cone_table_hit(sc.cone_tab, sc.cone_hdr, r.d, scan_from, near_lo, near_hi) : 0u;
                     const bool near_ok = (found & 2u) && cone_near_acceptable(sc.cone_tab, sc.prims_list, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max, near_lo, near_hi);
                     const bool from_cone = (found & 1u) && !near_ok;
                     if (!(found & 1u)) scan_from = 0;

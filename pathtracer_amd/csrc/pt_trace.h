@@ -21,6 +21,9 @@
 // ---------------------------------------------------------------------------------------------
 // Device-side views
 // ---------------------------------------------------------------------------------------------
+// the first words of the table cone_table_hit() searches (layout there)
+struct ConeTabHeader { uint32_t n, lo, hi, shift, nb; float flo, fhi; };
+
 struct SceneDev {
     const BvhNode *nodes;
     const PrimRec *prims;      // leaf (BVH) order
@@ -35,6 +38,7 @@ struct SceneDev {
     uint32_t n_wide4; // experiment: four-wide unquantised nodes (in `wide`) for the LDS-resident kernels
 #endif
     const uint32_t *cone_tab; // the cones' distinct slopes, for cone_table_hit(); null for a scene without cones
+    ConeTabHeader cone_hdr;   // its header words, as kernel arguments (a scalar load per look-up otherwise)
     pt::ConeParams cone; // how wide a cone the slab test gives a ray
     DeviceCamera cam;
     float bg[3];
@@ -149,19 +153,19 @@ PT_DI HitResult linear_nearest(const PrimRec *__restrict__ list, uint32_t n, con
 #define PT_CONE_TAB_MORE 0xFFFFFFFEu
 #define PT_CONE_TAB_NEAR (1.0f / 1048576.0f) // |a| up to this share of its terms counts as nearly cancelled (eight units in the last place at least)
 #define PT_CONE_TAB_SLACK 48u // q is off by at most six bit patterns (d_y^2, the reciprocal, the product and the reference's two products round once each); 2^-20 is 8 to 16 more, and their roundings 2
-PT_DI uint32_t cone_table_hit(const uint32_t *__restrict__ tab, v3 d, uint32_t &last_index, uint32_t &near_lo, uint32_t &near_hi)
+PT_DI uint32_t cone_table_hit(const uint32_t *__restrict__ tab, const ConeTabHeader &hd, v3 d, uint32_t &last_index, uint32_t &near_lo, uint32_t &near_hi)
 {
     const float S = d.x * d.x + d.z * d.z; // |d_xz|^2 as vlen2 of (d_x, 0, d_z) rounds it (cone.h:108, vec3.h:154-156)
     const float dy2 = d.y * d.y;
     last_index = 0;
     near_lo = 0xFFFFFFFFu;
     near_hi = 0;
-    if (!(S >= dy2 * __uint_as_float(tab[5]) && S <= dy2 * __uint_as_float(tab[6]))) return 0u; // (a NaN ends here too)
-    const uint32_t lo = tab[1], span = tab[2] - lo, shift = tab[3];
-    const uint32_t key = min(max(__float_as_uint(S * __builtin_amdgcn_rcpf(dy2)), lo), tab[2]) - lo;
+    if (!(S >= dy2 * hd.flo && S <= dy2 * hd.fhi)) return 0u; // (a NaN ends here too)
+    const uint32_t lo = hd.lo, span = hd.hi - lo, shift = hd.shift;
+    const uint32_t key = min(max(__float_as_uint(S * __builtin_amdgcn_rcpf(dy2)), lo), hd.hi) - lo;
     const uint32_t b0 = (key > PT_CONE_TAB_SLACK ? key - PT_CONE_TAB_SLACK : 0u) >> shift, b1 = min(key + PT_CONE_TAB_SLACK, span) >> shift;
     const uint4 *cells = reinterpret_cast<const uint4 *>(tab + PT_CONE_TAB_HEADER);
-    const uint32_t n = tab[0], nb = tab[4];
+    const uint32_t n = hd.n, nb = hd.nb;
     const float *val = reinterpret_cast<const float *>(tab + PT_CONE_TAB_HEADER + 4u * (size_t)nb);
     const uint32_t *last = reinterpret_cast<const uint32_t *>(val + n);
     const float tol = S * PT_CONE_TAB_NEAR;
@@ -224,7 +228,7 @@ PT_DI uint32_t cone_scan_from(const SceneDev &sc, const Ray &r, float t_min, flo
 {
     if (KIND != PT_KIND_ANY || !sc.cone_tab) return 0;
     uint32_t from = 0, near_lo, near_hi;
-    const uint32_t found = cone_table_hit(sc.cone_tab, r.d, from, near_lo, near_hi);
+    const uint32_t found = cone_table_hit(sc.cone_tab, sc.cone_hdr, r.d, from, near_lo, near_hi);
     if (!found) return 0;
     if ((found & 2u) && !cone_near_acceptable(sc.cone_tab, sc.prims_list, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, t_min, t_max, near_lo, near_hi) && !(found & 1u)) return 0;
     need_exact = true;
