@@ -492,7 +492,7 @@ static pt_status install_scene(pt_context *ctx, const pt_scene_desc *desc, const
     }
     // up to three entries per level; 31 is what five workgroups of 256 lanes leave each lane of the CU's LDS
     // (a ray that needs more is answered by the list scan and counted in exact_fallbacks)
-    sc.wide_stack_cap = want_wide ? std::min(31u, 3u * wb.max_depth + 2u) : 0u; // (with the bottom entry; 31 x 256 lanes x 4 B lets five workgroups share a CU's LDS)
+    sc.wide_stack_cap = want_wide ? std::min(PT_WIDE_STACK_MAX, 3u * wb.max_depth + 2u) : 0u; // (with the bottom entry; 31 x 256 lanes x 4 B lets five workgroups share a CU's LDS)
     ctx->wide_depth = want_wide ? wb.max_depth : 0u;
     sc.nodes = ctx->d_nodes;
     sc.prims = ctx->d_prims;

@@ -339,7 +339,9 @@ __global__ __launch_bounds__(BLOCK, PT_STREAM_WAVES) void k_paths_stream(SceneDe
                     if (n_hit == 0) {
                         node = (int32_t)stack[(--sp) * BLOCK];
                     } else {
-                        if (sp + n_hit - 1u > sc.wide_stack_cap) {
+                        // (against the constant, not sc.wide_stack_cap: a stack of fewer entries belongs to a tree too shallow to fill it, three
+                        // entries a level, and the compiler re-reads the kernel argument here with a scalar load and a wait in every step)
+                        if (sp + n_hit - 1u > PT_WIDE_STACK_MAX) {
                             by_list = true; // the stack cannot take them (deeper than 31 entries): the list answers this ray
                             node = PT_TRAVERSAL_DONE;
                         } else {

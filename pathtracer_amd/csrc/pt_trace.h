@@ -12,6 +12,7 @@
 #include "pt_device.h"
 
 #define PT_BLOCK 256
+#define PT_WIDE_STACK_MAX 31u // entries of the four-wide traversal's stack at most (what five workgroups of 256 lanes leave each lane of a CU's LDS)
 // what a scene holds (the kernels' KIND parameter; see bvh_nearest)
 #define PT_KIND_SPHERES 0
 #define PT_KIND_NO_CONES 1
